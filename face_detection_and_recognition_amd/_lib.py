@@ -1,0 +1,119 @@
+"""ctypes binding of libfacepath.so (the C ABI declared in include/facepath.h).
+
+There is no CPU fallback: if the shared library is missing or a symbol cannot be
+resolved, loading raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C face_detection_and_recognition_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfacepath.so")
+
+FP_OK = 0
+
+# fp_op_kind
+OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK = 1, 2, 3, 4, 5, 6, 7
+# fp_act
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
+# fp_res_mode
+RES_NONE, RES_ADD_BEFORE_ACT, RES_ADD_AFTER_ACT, RES_POOL2_BEFORE_ACT = 0, 1, 2, 3
+
+
+class FpOp(C.Structure):
+    """Mirror of struct fp_op (include/facepath.h)."""
+    _fields_ = [
+        ("kind", C.c_int32), ("act", C.c_int32), ("res_mode", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32),
+        ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+        ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("in_ld", C.c_int32), ("out_ld", C.c_int32), ("res_ld", C.c_int32),
+        ("out_cmul", C.c_int32), ("res_C", C.c_int32),
+        ("res_H", C.c_int32), ("res_W", C.c_int32),
+        ("in_ns", C.c_int64), ("out_ns", C.c_int64), ("res_ns", C.c_int64),
+        ("in_off", C.c_int64), ("out_off", C.c_int64), ("res_off", C.c_int64),
+        ("w_off", C.c_int64), ("scale_off", C.c_int64), ("bias_off", C.c_int64), ("slope_off", C.c_int64),
+    ]
+
+
+class FpResizeItem(C.Structure):
+    """Mirror of struct fp_resize_item."""
+    _fields_ = [("src_image", C.c_int32), ("sx", C.c_int32), ("sy", C.c_int32), ("sw", C.c_int32), ("sh", C.c_int32),
+                ("dx", C.c_int32), ("dy", C.c_int32), ("dw", C.c_int32), ("dh", C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_SZ = C.c_size_t
+_I64 = C.c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/facepath.h
+SIGNATURES = {
+    "fp_abi_version": (_I, []),
+    "fp_strerror": (C.c_char_p, [_I]),
+    "fp_last_hip_error": (C.c_char_p, []),
+    "fp_plan_run": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P]),
+    "fp_plan_validate": (_I, [C.POINTER(FpOp), _I, _SZ, _SZ]),
+    "fp_resize_normalize": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "fp_blaze_decode": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "fp_blaze_weighted_nms": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "fp_yolo_decode": (_I, [_P, _I, _I, _I, _I, _F, C.POINTER(_F), _P, _I64, _I64, _P]),
+    "fp_yolo_nms": (_I, [_P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "fp_yolo_nms_scratch_bytes": (_SZ, [_I, _I]),
+    "fp_yolo_w_nms": (_I, [_P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "fp_row_inv_norm": (_I, [_P, _I64, _I, _P, _P]),
+    "fp_cosine_filter": (_I, [_P, _P, _I64, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "fp_l2_mean_thres": (_I, [_P, _I, _I, _P, _P, _P]),
+    "fp_l2_filter": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class FacepathError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfacepath.so and bind every symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FacepathError(
+            f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU fallback. "
+            "Run `make -C face_detection_and_recognition_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.fp_abi_version()
+    if v != 1:
+        raise FacepathError(f"libfacepath ABI version {v}, expected 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != FP_OK:
+        lib = load()
+        msg = lib.fp_strerror(rc).decode()
+        hip = lib.fp_last_hip_error().decode()
+        raise FacepathError(f"{what}: {msg} (status {rc})" + (f" [HIP: {hip}]" if hip else ""))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    """The caller's current torch stream handle (so work is ordered with torch ops and graph-capturable)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,142 @@
+// capi.cpp — plan validation + executor and the small ABI utilities of libfacepath.so.
+// Compiled by hipcc as host code; kernels live in the .hip files.
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_hip_err[256] = "";
+
+void fp_set_hip_error(hipError_t e) {
+  const char* s = hipGetErrorString(e);
+  strncpy(g_hip_err, s ? s : "unknown", sizeof(g_hip_err) - 1);
+  g_hip_err[sizeof(g_hip_err) - 1] = 0;
+}
+
+extern "C" {
+
+int fp_abi_version(void) { return FP_ABI_VERSION; }
+
+const char* fp_last_hip_error(void) { return g_hip_err; }
+
+const char* fp_strerror(int status) {
+  switch (status) {
+    case FP_OK: return "ok";
+    case FP_ERR_INVALID_ARG: return "invalid argument";
+    case FP_ERR_BOUNDS: return "op touches memory outside the arena or weight blob";
+    case FP_ERR_UNSUPPORTED: return "unsupported op or parameter combination";
+    case FP_ERR_LAUNCH: return "HIP kernel launch failed";
+    case FP_ERR_ALIGNMENT: return "channel count / stride / offset not a multiple of 4 floats";
+    default: return "unknown status";
+  }
+}
+
+static bool span_ok(int64_t off, int64_t extent, size_t limit) {
+  return off >= 0 && extent >= 0 && (uint64_t)(off + extent) <= (uint64_t)limit;
+}
+
+static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_floats) {
+  if (op.N <= 0 || op.H <= 0 || op.W <= 0 || op.Cin <= 0) return FP_ERR_INVALID_ARG;
+  const bool spatial = op.kind != FP_OP_L2NORM && op.kind != FP_OP_COPY;
+  const int OH = spatial ? op.OH : op.H, OW = spatial ? op.OW : op.W;
+  if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
+  const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK) ? op.Cout : op.Cin;
+  if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
+  // input extent
+  const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
+  if (!span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
+  const int64_t out_ext =
+      (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (int64_t)(Cout - 1) * op.out_cmul + 1;
+  if (!span_ok(op.out_off, out_ext, arena_floats)) return FP_ERR_BOUNDS;
+  if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
+
+  if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK) {
+    if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
+    // every output pixel must have at least its first tap row/col addressable without overflow of int math
+    if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
+      return FP_ERR_INVALID_ARG;
+  }
+  if (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK) {
+    int64_t wext;
+    if (op.kind == FP_OP_CONV) {
+      const int64_t K = (int64_t)op.KH * op.KW * op.Cin;
+      wext = ((K + 7) / 8 * 8) * ((op.Cout + 31) / 32 * 32);
+    } else {
+      // BLAZEBLOCK: dw weights [9][Cin] followed (separately addressed) by the packed 1x1; w_off addresses the
+      // dw weights, scale_off the dw bias, slope_off the packed pointwise weights, bias_off the pointwise bias.
+      wext = 9 * (int64_t)op.Cin;
+      const int64_t pw = ((op.Cin + 7) / 8 * 8) * (int64_t)((op.Cout + 31) / 32 * 32);
+      if (!span_ok(op.slope_off, pw, weight_floats)) return FP_ERR_BOUNDS;
+      if (!span_ok(op.scale_off, op.Cin, weight_floats)) return FP_ERR_BOUNDS;
+      if (!span_ok(op.bias_off, op.Cout, weight_floats)) return FP_ERR_BOUNDS;
+    }
+    if (!span_ok(op.w_off, wext, weight_floats)) return FP_ERR_BOUNDS;
+  }
+  if (op.kind == FP_OP_DWCONV) {
+    if (!span_ok(op.w_off, (int64_t)op.KH * op.KW * op.Cin, weight_floats)) return FP_ERR_BOUNDS;
+  }
+  if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV) {
+    if (op.scale_off >= 0 && !span_ok(op.scale_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
+    if (op.bias_off >= 0 && !span_ok(op.bias_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
+    if (op.slope_off >= 0 && !span_ok(op.slope_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
+    if (op.act == FP_ACT_PRELU && op.slope_off < 0) return FP_ERR_INVALID_ARG;
+    if (op.act < FP_ACT_NONE || op.act > FP_ACT_SILU) return FP_ERR_INVALID_ARG;
+  }
+  if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK) && op.res_mode != FP_RES_NONE) {
+    if (op.res_mode < FP_RES_NONE || op.res_mode > FP_RES_POOL2_BEFORE_ACT) return FP_ERR_INVALID_ARG;
+    if (op.res_C <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
+    int rh = OH, rw = OW;
+    if (op.res_mode == FP_RES_POOL2_BEFORE_ACT) {
+      rh = op.res_H;
+      rw = op.res_W;
+      if (rh < 2 * OH || rw < 2 * OW) return FP_ERR_INVALID_ARG;
+    }
+    const int64_t res_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)rh * rw - 1) * op.res_ld + op.res_C;
+    if (!span_ok(op.res_off, res_ext, arena_floats)) return FP_ERR_BOUNDS;
+  }
+  switch (op.kind) {
+    case FP_OP_CONV:
+    case FP_OP_DWCONV:
+    case FP_OP_MAXPOOL:
+    case FP_OP_UPSAMPLE2X:
+    case FP_OP_COPY:
+    case FP_OP_L2NORM:
+    case FP_OP_BLAZEBLOCK:
+      return FP_OK;
+    default:
+      return FP_ERR_UNSUPPORTED;
+  }
+}
+
+int fp_plan_validate(const fp_op* ops, int n_ops, size_t weight_floats, size_t arena_floats) {
+  if (!ops || n_ops < 0) return FP_ERR_INVALID_ARG;
+  for (int i = 0; i < n_ops; ++i) {
+    int rc = validate_op(ops[i], weight_floats, arena_floats);
+    if (rc != FP_OK) return rc;
+  }
+  return FP_OK;
+}
+
+int fp_plan_run(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
+                size_t arena_floats, void* stream) {
+  if (!weights || !arena) return FP_ERR_INVALID_ARG;
+  int rc = fp_plan_validate(ops, n_ops, weight_floats, arena_floats);
+  if (rc != FP_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_ops; ++i) {
+    const fp_op& op = ops[i];
+    switch (op.kind) {
+      case FP_OP_CONV: rc = fp_launch_conv(op, weights, arena, s); break;
+      case FP_OP_DWCONV: rc = fp_launch_dwconv(op, weights, arena, s); break;
+      case FP_OP_MAXPOOL: rc = fp_launch_maxpool(op, arena, s); break;
+      case FP_OP_UPSAMPLE2X: rc = fp_launch_upsample2x(op, arena, s); break;
+      case FP_OP_COPY: rc = fp_launch_copy(op, arena, s); break;
+      case FP_OP_L2NORM: rc = fp_launch_l2norm(op, arena, s); break;
+      case FP_OP_BLAZEBLOCK: rc = fp_launch_blazeblock(op, weights, arena, s); break;
+      default: rc = FP_ERR_UNSUPPORTED;
+    }
+    if (rc != FP_OK) return rc;
+  }
+  return FP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Internal helpers shared by the HIP translation units of libfacepath.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/facepath.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FP_WAVE 64
+
+// Per-thread record of the last HIP error text (fp_last_hip_error()).
+void fp_set_hip_error(hipError_t e);
+
+#define FP_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) {                      \
+      fp_set_hip_error(e__);                      \
+      return FP_ERR_LAUNCH;                       \
+    }                                             \
+  } while (0)
+
+static inline int fp_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long fp_round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+// launchers implemented in the .hip files, called by the plan executor (capi.cpp)
+int fp_launch_conv(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+int fp_launch_dwconv(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+int fp_launch_maxpool(const fp_op& op, float* arena, hipStream_t s);
+int fp_launch_upsample2x(const fp_op& op, float* arena, hipStream_t s);
+int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s);
+int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s);
+int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);

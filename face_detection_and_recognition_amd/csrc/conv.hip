@@ -1,0 +1,482 @@
+// conv.hip — dense convolution as an fp32-MFMA implicit GEMM with a fused epilogue (gfx950).
+//
+// Replaces, for the hot path, every nn.Conv2d that is not depthwise:
+//   BlazeFace stem 5x5 s2 + 1x1 convs + heads (fde/modules/blazeface/blazeface.py:29-33,118-120,155-159)
+//   Mobile-FaceNet conv1 / 1x1 expand / 1x1 project / Linear (fde/modules/mobile_facenet/mobile_facenet.py:39-64,135)
+//   YOLOv5-face Conv k in {1,3}, s in {1,2} (+folded or live BN, SiLU) (y5/models/common.py:39-55,127-176)
+//
+// GEMM view: M = N*OH*OW output pixels, Kdim = KH*KW*Cin, Ncol = Cout.  Activations are NHWC, so for a
+// 1x1 conv the A panel of a block is one contiguous byte range.  A block owns 128 rows x (NB*32) columns;
+// each of its 4 waves owns 32 rows and NB 32x32 accumulators (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+// Per 32-deep K chunk the block stages A (gathered im2col rows, zero padded) and the packed weights into
+// LDS with 16-byte accesses; the next chunk's global loads are issued before the current chunk's MFMAs and
+// written to LDS after them (register prefetch).  Fragments are read with one ds_read_b128 per 4 MFMA
+// k-steps: lane (r = lane&31, h = lane>>5) holds A[r][8g+4h .. 8g+4h+3] and B[8g+4h .. +3][r], i.e. k-step t
+// multiplies k = 8g+t (h=0) and 8g+4+t (h=1) — a permutation of the k order, which a sum does not care about.
+// LDS row stride for A is 36 floats (144 B): 16 consecutive rows hit 16 distinct 16-B slots -> conflict free.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* in;
+  float* out;
+  const float* res;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* slope;
+  int N, H, W, OH, OW, Cin, Cout, KH, KW, stride, pad_t, pad_l;
+  int in_ld, out_ld, res_ld, out_cmul, res_C, res_H, res_W;
+  long in_ns, out_ns, res_ns;
+  int act, res_mode;
+  int K, Kpad, Npad, OHW;
+  long M;
+};
+
+constexpr int BM = 128;
+constexpr int KC = 32;
+constexpr int LDA = KC + 4;
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case FP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case FP_ACT_PRELU: return v > 0.f ? v : v * slope;
+    case FP_ACT_SILU: return v / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+template <int NB, bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int BN = NB * 32;
+  __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[(KC / 4) * BN * 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // A staging: thread -> k-quad column c4 (0..7) and rows r0 + 32*i
+  const int c4 = tid & 7;
+  const int r0 = tid >> 3;
+  long pixbase[4];  // img*in_ns, folded with validity
+  int iy0[4], ix0[4];
+  bool rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long m = m0 + r0 + 32 * i;
+    rv[i] = m < p.M;
+    long mm = rv[i] ? m : 0;
+    int img = (int)(mm / p.OHW);
+    int rem = (int)(mm - (long)img * p.OHW);
+    int oy = rem / p.OW, ox = rem - oy * p.OW;
+    pixbase[i] = (long)img * p.in_ns;
+    iy0[i] = oy * p.stride - p.pad_t;
+    ix0[i] = ox * p.stride - p.pad_l;
+  }
+
+  f32x4 areg[4];
+  f32x4 breg[NB];
+  const int KHW = p.KH * p.KW;
+
+  auto load_chunk = [&](int kbase) {
+    if (VEC) {
+      const int k4 = kbase + c4 * 4;
+      const bool kv = k4 < p.K;
+      int tap = 0, c = k4;
+      if (KHW > 1) {
+        tap = k4 / p.Cin;
+        c = k4 - tap * p.Cin;
+      }
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        const bool ok = kv && rv[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *(const f32x4*)(p.in + pixbase[i] + ((long)iy * p.W + ix) * p.in_ld + c);
+        areg[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = kbase + c4 * 4 + e;
+          if (k < p.K && rv[i]) {
+            const int tap = k / p.Cin, c = k - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+              v[e] = p.in[pixbase[i] + ((long)iy * p.W + ix) * p.in_ld + c];
+          }
+        }
+        areg[i] = v;
+      }
+    }
+    const int q0 = kbase >> 2;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int idx = tid + 256 * j;
+      const int q = idx / BN, col = idx - q * BN;
+      const int gq = q0 + q, n = n0 + col;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gq < (p.Kpad >> 2) && n < p.Npad) v = *(const f32x4*)(p.w + ((long)gq * p.Npad + n) * 4);
+      breg[j] = v;
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)&As[(r0 + 32 * i) * LDA + c4 * 4] = areg[i];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *(f32x4*)&Bs[(tid + 256 * j) * 4] = breg[j];
+  };
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const int nchunks = (p.Kpad + KC - 1) / KC;
+  load_chunk(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    store_chunk();
+    __syncthreads();
+    if (ch + 1 < nchunks) load_chunk((ch + 1) * KC);
+    const int kleft = p.Kpad - ch * KC;
+    const int kqmax = kleft >= KC ? KC / 8 : kleft / 8;
+    const float* arow = &As[(wave * 32 + lr) * LDA + 4 * h];
+#pragma unroll
+    for (int kq = 0; kq < KC / 8; ++kq) {
+      if (kq < kqmax) {
+        const f32x4 a = *(const f32x4*)(arow + kq * 8);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const f32x4 b = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[nb], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // Epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    const long m = m0 + wave * 32 + row;
+    if (m >= p.M) continue;
+    const int img = (int)(m / p.OHW);
+    const int pix = (int)(m - (long)img * p.OHW);
+    float* orow = p.out + (long)img * p.out_ns + (long)pix * p.out_ld;
+    const float* rrow = nullptr;
+    const float* rrow2 = nullptr;
+    if (p.res_mode == FP_RES_ADD_BEFORE_ACT || p.res_mode == FP_RES_ADD_AFTER_ACT) {
+      rrow = p.res + (long)img * p.res_ns + (long)pix * p.res_ld;
+    } else if (p.res_mode == FP_RES_POOL2_BEFORE_ACT) {
+      const int oy = pix / p.OW, ox = pix - oy * p.OW;
+      rrow = p.res + (long)img * p.res_ns + ((long)(2 * oy) * p.res_W + 2 * ox) * p.res_ld;
+      rrow2 = rrow + (long)p.res_W * p.res_ld;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + nb * 32 + lr;
+      if (n >= p.Cout) continue;
+      float v = acc[nb][reg];
+      if (p.scale) v *= p.scale[n];
+      if (p.bias) v += p.bias[n];
+      float r = 0.f;
+      if (rrow && n < p.res_C) {
+        if (rrow2) {
+          const float a0 = rrow[n], a1 = rrow[p.res_ld + n];
+          const float b0 = rrow2[n], b1 = rrow2[p.res_ld + n];
+          r = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+        } else {
+          r = rrow[n];
+        }
+      }
+      const float sl = (p.act == FP_ACT_PRELU) ? p.slope[n] : 0.f;
+      if (p.res_mode == FP_RES_ADD_AFTER_ACT)
+        v = apply_act(v, p.act, sl) + r;
+      else
+        v = apply_act(v + r, p.act, sl);
+      orow[(long)n * p.out_cmul] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise KSxKS convolution, one thread = one output pixel x 4 channels (16-B accesses, NHWC).
+// BlazeBlock convs[0] (blazeface.py:26-29), Mobile-FaceNet conv_dw / conv_6_dw (mobile_facenet.py:72-73,130),
+// ShuffleV2Block.depthwise_conv (y5/models/common.py:166-167).  HBM-bound: neighbours re-read through L1/L2.
+struct DwArgs {
+  const float* in;
+  float* out;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* slope;
+  int N, H, W, OH, OW, C, stride, pad_t, pad_l;
+  int in_ld, out_ld;
+  long in_ns, out_ns;
+  int act, OHW, C4;
+  long total;  // M * C4
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int c4 = (int)(idx % p.C4);
+  const long m = idx / p.C4;
+  const int img = (int)(m / p.OHW);
+  const int pix = (int)(m - (long)img * p.OHW);
+  const int oy = pix / p.OW, ox = pix - oy * p.OW;
+  const int c = c4 * 4;
+  const float* ibase = p.in + (long)img * p.in_ns + c;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky) {
+    const int iy = oy * p.stride - p.pad_t + ky;
+    if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const int ix = ox * p.stride - p.pad_l + kx;
+      if (ix < 0 || ix >= p.W) continue;
+      const f32x4 x = *(const f32x4*)(ibase + ((long)iy * p.W + ix) * p.in_ld);
+      const f32x4 wv = *(const f32x4*)(p.w + (ky * KS + kx) * p.C + c);
+      acc += x * wv;
+    }
+  }
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = acc[e];
+    if (p.scale) v *= p.scale[c + e];
+    if (p.bias) v += p.bias[c + e];
+    o[e] = apply_act(v, p.act, p.act == FP_ACT_PRELU ? p.slope[c + e] : 0.f);
+  }
+  *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c) = o;
+}
+
+// Max pooling (nn.MaxPool2d: y5/models/common.py:64,186-187; padding behaves as -inf).
+struct PoolArgs {
+  const float* in;
+  float* out;
+  int N, H, W, OH, OW, C, K, stride, pad_t, pad_l, in_ld, out_ld;
+  long in_ns, out_ns;
+  int OHW, C4;
+  long total;
+};
+
+__global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int c4 = (int)(idx % p.C4);
+  const long m = idx / p.C4;
+  const int img = (int)(m / p.OHW);
+  const int pix = (int)(m - (long)img * p.OHW);
+  const int oy = pix / p.OW, ox = pix - oy * p.OW;
+  const float* ibase = p.in + (long)img * p.in_ns + c4 * 4;
+  const float ninf = -__builtin_huge_valf();
+  f32x4 acc = {ninf, ninf, ninf, ninf};
+  for (int ky = 0; ky < p.K; ++ky) {
+    const int iy = oy * p.stride - p.pad_t + ky;
+    if (iy < 0 || iy >= p.H) continue;
+    for (int kx = 0; kx < p.K; ++kx) {
+      const int ix = ox * p.stride - p.pad_l + kx;
+      if (ix < 0 || ix >= p.W) continue;
+      const f32x4 x = *(const f32x4*)(ibase + ((long)iy * p.W + ix) * p.in_ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], x[e]);
+    }
+  }
+  *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c4 * 4) = acc;
+}
+
+// nn.Upsample(scale_factor=2, mode='nearest') (y5/models/yolov5n.yaml:26,31) writing into a concat slice.
+__global__ __launch_bounds__(256) void upsample2x_kernel(PoolArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int c4 = (int)(idx % p.C4);
+  const long m = idx / p.C4;
+  const int img = (int)(m / p.OHW);
+  const int pix = (int)(m - (long)img * p.OHW);
+  const int oy = pix / p.OW, ox = pix - oy * p.OW;
+  const f32x4 x = *(const f32x4*)(p.in + (long)img * p.in_ns + ((long)(oy >> 1) * p.W + (ox >> 1)) * p.in_ld + c4 * 4);
+  *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c4 * 4) = x;
+}
+
+// Channel-slice copy with an output channel multiplier: torch.cat / chunk / channel_shuffle
+// (y5/models/common.py:21-31,169-176,241-242).  Scalar because out_cmul = 2 interleaves.
+struct CopyArgs {
+  const float* in;
+  float* out;
+  int C, in_ld, out_ld, out_cmul, HW;
+  long in_ns, out_ns, total;
+};
+
+__global__ __launch_bounds__(256) void copy_kernel(CopyArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int c = (int)(idx % p.C);
+  const long m = idx / p.C;
+  const int img = (int)(m / p.HW);
+  const int pix = (int)(m - (long)img * p.HW);
+  p.out[(long)img * p.out_ns + (long)pix * p.out_ld + (long)c * p.out_cmul] =
+      p.in[(long)img * p.in_ns + (long)pix * p.in_ld + c];
+}
+
+// l2_norm (mobile_facenet.py:30-33): one wave per row, x / sqrt(sum x^2), no epsilon.
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* in, float* out, long M, int D, long in_ld, long out_ld) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = in + row * in_ld;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += x[i] * x[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float nrm = sqrtf(s);
+  for (int i = lane; i < D; i += 64) out[row * out_ld + i] = x[i] / nrm;
+}
+
+}  // namespace
+
+int fp_launch_conv(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  ConvArgs a;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.res = op.res_mode != FP_RES_NONE ? arena + op.res_off : nullptr;
+  a.w = weights + op.w_off;
+  a.scale = op.scale_off >= 0 ? weights + op.scale_off : nullptr;
+  a.bias = op.bias_off >= 0 ? weights + op.bias_off : nullptr;
+  a.slope = op.slope_off >= 0 ? weights + op.slope_off : nullptr;
+  a.N = op.N; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW;
+  a.Cin = op.Cin; a.Cout = op.Cout; a.KH = op.KH; a.KW = op.KW; a.stride = op.stride;
+  a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+  a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.res_ld = op.res_ld; a.out_cmul = op.out_cmul;
+  a.res_C = op.res_C; a.res_H = op.res_H; a.res_W = op.res_W;
+  a.in_ns = op.in_ns; a.out_ns = op.out_ns; a.res_ns = op.res_ns;
+  a.act = op.act; a.res_mode = op.res_mode;
+  a.K = op.KH * op.KW * op.Cin;
+  a.Kpad = (int)fp_round_up(a.K, 8);
+  a.Npad = (int)fp_round_up(op.Cout, 32);
+  a.OHW = op.OH * op.OW;
+  a.M = (long)op.N * a.OHW;
+  if (a.act == FP_ACT_PRELU && !a.slope) return FP_ERR_INVALID_ARG;
+  const bool vec = (op.Cin % 4 == 0) && (op.in_ld % 4 == 0) && (op.in_off % 4 == 0) && (op.in_ns % 4 == 0);
+  const int nblk32 = a.Npad / 32;
+  int NB = 4;
+  if (nblk32 % 4 == 0) NB = 4;
+  else if (nblk32 % 3 == 0) NB = 3;
+  else if (nblk32 % 2 == 0) NB = 2;
+  else if (nblk32 == 1) NB = 1;
+  else NB = 4;  // partial last tile (guarded in-kernel)
+  dim3 grid((unsigned)fp_ceil_div(a.M, BM), (unsigned)fp_ceil_div(a.Npad, NB * 32));
+  dim3 block(256);
+#define FP_CONV_CASE(NBV)                                                         \
+  case NBV:                                                                       \
+    if (vec) hipLaunchKernelGGL((conv_igemm_kernel<NBV, true>), grid, block, 0, s, a);  \
+    else hipLaunchKernelGGL((conv_igemm_kernel<NBV, false>), grid, block, 0, s, a);     \
+    break;
+  switch (NB) {
+    FP_CONV_CASE(1)
+    FP_CONV_CASE(2)
+    FP_CONV_CASE(3)
+    FP_CONV_CASE(4)
+  }
+#undef FP_CONV_CASE
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+int fp_launch_dwconv(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  if (op.Cin % 4 || op.in_ld % 4 || op.out_ld % 4 || op.in_off % 4 || op.out_off % 4 || op.in_ns % 4 || op.out_ns % 4 ||
+      op.out_cmul != 1)
+    return FP_ERR_ALIGNMENT;
+  if (op.KH != op.KW) return FP_ERR_UNSUPPORTED;
+  DwArgs a;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.w = weights + op.w_off;
+  a.scale = op.scale_off >= 0 ? weights + op.scale_off : nullptr;
+  a.bias = op.bias_off >= 0 ? weights + op.bias_off : nullptr;
+  a.slope = op.slope_off >= 0 ? weights + op.slope_off : nullptr;
+  a.N = op.N; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.C = op.Cin;
+  a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+  a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  a.act = op.act; a.OHW = op.OH * op.OW; a.C4 = op.Cin / 4;
+  a.total = (long)op.N * a.OHW * a.C4;
+  if (a.act == FP_ACT_PRELU && !a.slope) return FP_ERR_INVALID_ARG;
+  dim3 grid((unsigned)fp_ceil_div(a.total, 256)), block(256);
+  switch (op.KH) {
+    case 3: hipLaunchKernelGGL((dwconv_kernel<3>), grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((dwconv_kernel<5>), grid, block, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((dwconv_kernel<7>), grid, block, 0, s, a); break;
+    default: return FP_ERR_UNSUPPORTED;
+  }
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+static int fill_pool_args(const fp_op& op, float* arena, PoolArgs& a) {
+  if (op.Cin % 4 || op.in_ld % 4 || op.out_ld % 4 || op.in_off % 4 || op.out_off % 4 || op.in_ns % 4 || op.out_ns % 4 ||
+      op.out_cmul != 1)
+    return FP_ERR_ALIGNMENT;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.N = op.N; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.C = op.Cin;
+  a.K = op.KH; a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+  a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  a.OHW = op.OH * op.OW; a.C4 = op.Cin / 4;
+  a.total = (long)op.N * a.OHW * a.C4;
+  return FP_OK;
+}
+
+int fp_launch_maxpool(const fp_op& op, float* arena, hipStream_t s) {
+  PoolArgs a;
+  int rc = fill_pool_args(op, arena, a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+int fp_launch_upsample2x(const fp_op& op, float* arena, hipStream_t s) {
+  PoolArgs a;
+  int rc = fill_pool_args(op, arena, a);
+  if (rc) return rc;
+  if (op.OH != 2 * op.H || op.OW != 2 * op.W) return FP_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s) {
+  CopyArgs a;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.C = op.Cin; a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.out_cmul = op.out_cmul;
+  a.HW = op.H * op.W; a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  a.total = (long)op.N * a.HW * a.C;
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s) {
+  const long M = (long)op.N * op.H * op.W;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)fp_ceil_div(M, 4)), dim3(256), 0, s, arena + op.in_off,
+                     arena + op.out_off, M, op.Cin, (long)op.in_ld, (long)op.out_ld);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}

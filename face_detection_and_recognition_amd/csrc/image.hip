@@ -1,0 +1,108 @@
+// image.hip — u8 frame -> normalised fp32 NHWC canvas (letterbox and per-face crop), gfx950.
+//
+// Replaces pad_resize_image (fde/modules/utils/image.py:31-59: cv2.resize bilinear + copyMakeBorder 125),
+// the BGR->RGB flip and the three normalisations (blazeface.py:248-250, y5/__init__.py:15-20,
+// mobile_facenet/utils.py:13-16) and the crop->resize of extract_faces_from_dataset.py:289-303.
+// The resize follows OpenCV's INTER_LINEAR scheme for 8-bit images: 11-bit fixed-point coefficients
+// (saturate_cast<short>(w * 2048), round-half-even), horizontal pass in int, vertical pass
+//   ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2.
+// cv2 is absent offline, so this boundary is parity-unpinned against cv2 itself and pinned
+// against oracle/image_ref.py, which restates the same arithmetic in numpy.
+// One thread per canvas pixel; HBM-bound (reads each source byte once, writes 16 B per pixel).
+#include "common.h"
+
+namespace {
+
+struct ResizeArgs {
+  const uint8_t* frames;
+  const fp_resize_item* items;
+  float* canvas;
+  const float* lut;
+  int n_frames, fh, fw, n_items, ch, cw, cc, pad_value, swap_rb;
+};
+
+__device__ __forceinline__ void coef(int d, double scale, int ssize, int& s0, int& s1, int& a0, int& a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) {
+    f = 0.f;
+    s = 0;
+  }
+  if (s >= ssize - 1) {
+    f = 0.f;
+    s = ssize - 1;
+  }
+  s0 = s;
+  s1 = min(s + 1, ssize - 1);
+  a0 = (int)rintf((1.f - f) * 2048.f);
+  a1 = (int)rintf(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void resize_normalize_kernel(ResizeArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)p.ch * p.cw;
+  if (idx >= per * p.n_items) return;
+  const int item = (int)(idx / per);
+  const int pix = (int)(idx - (long)item * per);
+  const int y = pix / p.cw, x = pix - y * p.cw;
+  fp_resize_item it = p.items[item];
+  // items live in device memory (they can come straight from the NMS kernels), so the source
+  // rectangle is clamped here: a bad box can shrink the crop but never read outside the frame.
+  it.sx = min(max(it.sx, 0), p.fw - 1);
+  it.sy = min(max(it.sy, 0), p.fh - 1);
+  it.sw = min(max(it.sw, 1), p.fw - it.sx);
+  it.sh = min(max(it.sh, 1), p.fh - it.sy);
+  int v[3];
+  const bool inside = it.dw > 0 && it.dh > 0 && x >= it.dx && x < it.dx + it.dw && y >= it.dy &&
+                      y < it.dy + it.dh && it.src_image >= 0 && it.src_image < p.n_frames;
+  if (inside) {
+    int sx0, sx1, ax0, ax1, sy0, sy1, by0, by1;
+    coef(x - it.dx, (double)it.sw / (double)it.dw, it.sw, sx0, sx1, ax0, ax1);
+    coef(y - it.dy, (double)it.sh / (double)it.dh, it.sh, sy0, sy1, by0, by1);
+    const uint8_t* f = p.frames + (long)it.src_image * p.fh * p.fw * 3;
+    const uint8_t* r0 = f + ((long)(it.sy + sy0) * p.fw + it.sx) * 3;
+    const uint8_t* r1 = f + ((long)(it.sy + sy1) * p.fw + it.sx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int h0 = (int)r0[sx0 * 3 + c] * ax0 + (int)r0[sx1 * 3 + c] * ax1;
+      const int h1 = (int)r1[sx0 * 3 + c] * ax0 + (int)r1[sx1 * 3 + c] * ax1;
+      int o = (((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      v[c] = min(max(o, 0), 255);
+    }
+  } else {
+    v[0] = v[1] = v[2] = p.pad_value;
+  }
+  float* o = p.canvas + ((long)item * per + pix) * p.cc;
+  const float c0 = p.lut[p.swap_rb ? v[2] : v[0]];
+  const float c1 = p.lut[v[1]];
+  const float c2 = p.lut[p.swap_rb ? v[0] : v[2]];
+  if (p.cc == 4) {
+    f32x4 w = {c0, c1, c2, 0.f};
+    *(f32x4*)o = w;
+  } else {
+    o[0] = c0;
+    o[1] = c1;
+    o[2] = c2;
+    for (int c = 3; c < p.cc; ++c) o[c] = 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int frame_w,
+                                   const fp_resize_item* items, int n_items, float* canvas, int canvas_h, int canvas_w,
+                                   int canvas_c, const float* lut256, int pad_value, int swap_rb, void* stream) {
+  if (!frames || !items || !canvas || !lut256) return FP_ERR_INVALID_ARG;
+  if (n_frames <= 0 || frame_h <= 0 || frame_w <= 0 || n_items < 0 || canvas_h <= 0 || canvas_w <= 0 || canvas_c < 3)
+    return FP_ERR_INVALID_ARG;
+  if (pad_value < 0 || pad_value > 255) return FP_ERR_INVALID_ARG;
+  if (n_items == 0) return FP_OK;
+  ResizeArgs a{frames, items, canvas, lut256, n_frames, frame_h, frame_w, n_items, canvas_h, canvas_w, canvas_c,
+               pad_value, swap_rb};
+  const long total = (long)n_items * canvas_h * canvas_w;
+  hipLaunchKernelGGL(resize_normalize_kernel, dim3((unsigned)fp_ceil_div(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}

@@ -1,0 +1,291 @@
+"""BlazeFace on MI355X: same classes, attributes and ``state_dict`` keys as the reference
+(face_detection_and_extraction/modules/blazeface/blazeface.py), with the arithmetic in HIP:
+
+  forward (blazeface.py:192-228)                 -> fp_plan_run   (csrc/conv.hip, csrc/blaze.hip)
+  _tensors_to_detections/_decode_boxes (:321-402) -> fp_blaze_decode        (csrc/post.hip)
+  _weighted_non_max_suppression (:404-458)        -> fp_blaze_weighted_nms  (csrc/post.hip)
+  _preprocess x/127.5-1 (:248-250)                -> LUT inside fp_resize_normalize (csrc/image.hip)
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ...plan import Buf, CompiledPlan, PlanBuilder, View, cpad
+from ..params import ConvParams, _NoCompute, npy
+
+
+class BlazeBlock(_NoCompute):
+    """blazeface.py:12-47.  convs = [depthwise kxk (stride s), pointwise 1x1]; shortcut = x or
+    maxpool2(x), zero-padded on channels; ReLU(convs(h) + shortcut)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1):
+        super().__init__()
+        self.stride = stride
+        self.channel_pad = out_channels - in_channels
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        padding = 0 if stride == 2 else (kernel_size - 1) // 2
+        self.convs = nn.Sequential(
+            ConvParams(in_channels, in_channels, kernel_size, stride, padding, groups=in_channels, bias=True),
+            ConvParams(in_channels, out_channels, 1, 1, 0, bias=True))
+
+    def emit(self, pb, x):
+        dw, pw = self.convs[0], self.convs[1]
+        if self.stride == 2:
+            # h = F.pad(x, (0, 2, 0, 2)); dw stride 2, padding 0 (blazeface.py:38-39)
+            OH, OW, pad = x.H // 2, x.W // 2, (0, 0)
+            res_mode = L.RES_POOL2_BEFORE_ACT
+        else:
+            OH, OW, pad = x.H, x.W, (1, 1)
+            res_mode = L.RES_ADD_BEFORE_ACT
+        t = pb.new_buf(OH, OW, self.in_channels)
+        pb.dwconv(x, npy(dw.weight), t.view(), stride=self.stride, pad=pad, bias=npy(dw.bias))
+        y = pb.new_buf(OH, OW, self.out_channels)
+        res = View(x.buf, x.coff, min(self.in_channels, x.C))
+        pb.conv(t.view(), npy(pw.weight), y.view(), bias=npy(pw.bias), act=L.ACT_RELU, res=res, res_mode=res_mode)
+        pb.free(t)
+        return y
+
+
+class FinalBlazeBlock(_NoCompute):
+    """blazeface.py:50-68: pad (0,2,0,2), dw 3x3 s2, 1x1, ReLU, no shortcut."""
+
+    def __init__(self, channels, kernel_size=3):
+        super().__init__()
+        self.channels = channels
+        self.convs = nn.Sequential(
+            ConvParams(channels, channels, kernel_size, 2, 0, groups=channels, bias=True),
+            ConvParams(channels, channels, 1, 1, 0, bias=True))
+
+    def emit(self, pb, x):
+        dw, pw = self.convs[0], self.convs[1]
+        OH, OW = x.H // 2, x.W // 2
+        t = pb.new_buf(OH, OW, self.channels)
+        pb.dwconv(x, npy(dw.weight), t.view(), stride=2, pad=(0, 0), bias=npy(dw.bias))
+        y = pb.new_buf(OH, OW, self.channels)
+        pb.conv(t.view(), npy(pw.weight), y.view(), bias=npy(pw.bias), act=L.ACT_RELU)
+        pb.free(t)
+        return y
+
+
+class _ReLUTag(_NoCompute):
+    """Placeholder for nn.ReLU in the backbone Sequential so child indices (state_dict keys) match."""
+
+
+def generate_anchors(back_model=False):
+    """MediaPipe SSD anchors for BlazeFace (the reference loads them from anchors.npy / anchorsback.npy,
+    blazeface.py:238-246, files that do not ship in the tree).  896 rows (x_center, y_center, 1, 1):
+    a 16x16 grid with 2 anchors per cell, then an 8x8 grid with 6 (fixed_anchor_size, aspect ratio 1)."""
+    rows = []
+    for grid, per_cell in ((16, 2), (8, 6)):
+        for y in range(grid):
+            for x in range(grid):
+                for _ in range(per_cell):
+                    rows.append([(x + 0.5) / grid, (y + 0.5) / grid, 1.0, 1.0])
+    return np.asarray(rows, dtype=np.float32)
+
+
+class BlazeFace(nn.Module):
+    """blazeface.py:71-458.  ``forward(x)`` takes the pre-processed NCHW float batch and returns ``[r, c]``
+    with r (b, 896, 16) and c (b, 896, 1); ``predict_on_batch`` returns a list of (k, 17) tensors
+    (ymin, xmin, ymax, xmax, 6 keypoints, score)."""
+
+    def __init__(self, back_model=False):
+        super().__init__()
+        self.num_classes = 1
+        self.num_anchors = 896
+        self.num_coords = 16
+        self.score_clipping_thresh = 100.0
+        self.back_model = back_model
+        if back_model:
+            self.x_scale = self.y_scale = self.h_scale = self.w_scale = 256.0
+            self.min_score_thresh = 0.65
+        else:
+            self.x_scale = self.y_scale = self.h_scale = self.w_scale = 128.0
+            self.min_score_thresh = 0.75
+        self.min_suppression_threshold = 0.3
+        self.anchors = None
+        self._plans = {}
+        self._define_layers()
+
+    def _define_layers(self):
+        stem = [ConvParams(3, 24, 5, 2, 0, bias=True), _ReLUTag()]
+        if self.back_model:
+            spec = ([(24, 24, 1)] * 7 + [(24, 24, 2)] + [(24, 24, 1)] * 7 + [(24, 48, 2)] + [(48, 48, 1)] * 7 +
+                    [(48, 96, 2)] + [(96, 96, 1)] * 7)
+            self.backbone = nn.Sequential(*stem, *[BlazeBlock(i, o, stride=s) for i, o, s in spec])
+            self.final = FinalBlazeBlock(96)
+            c8 = 96
+        else:
+            spec1 = [(24, 24, 1), (24, 28, 1), (28, 32, 2), (32, 36, 1), (36, 42, 1), (42, 48, 2), (48, 56, 1),
+                     (56, 64, 1), (64, 72, 1), (72, 80, 1), (80, 88, 1)]
+            spec2 = [(88, 96, 2)] + [(96, 96, 1)] * 4
+            self.backbone1 = nn.Sequential(*stem, *[BlazeBlock(i, o, stride=s) for i, o, s in spec1])
+            self.backbone2 = nn.Sequential(*[BlazeBlock(i, o, stride=s) for i, o, s in spec2])
+            c8 = 88
+        self.classifier_8 = ConvParams(c8, 2, 1, bias=True)
+        self.classifier_16 = ConvParams(96, 6, 1, bias=True)
+        self.regressor_8 = ConvParams(c8, 32, 1, bias=True)
+        self.regressor_16 = ConvParams(96, 96, 1, bias=True)
+
+    # ------------------------------------------------------------------ loading
+    def _device(self):
+        return self.classifier_8.weight.device
+
+    def load_weights(self, path):
+        self.load_state_dict(torch.load(path, weights_only=True))
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._plans = {}
+        return out
+
+    def load_anchors(self, path, use_numpy=False):
+        arr = np.load(path).astype(np.float32)
+        self.set_anchors(arr)
+
+    def set_anchors(self, arr):
+        arr = np.asarray(arr, dtype=np.float32)
+        assert arr.ndim == 2 and arr.shape[0] == self.num_anchors and arr.shape[1] == 4
+        self.anchors = torch.tensor(arr, dtype=torch.float32, device=self._device())
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._plans = {}
+        if self.anchors is not None:
+            self.anchors = fn(self.anchors)
+        return out
+
+    # ------------------------------------------------------------------ plan
+    @property
+    def input_hw(self):
+        return (256, 256) if self.back_model else (128, 128)
+
+    def _emit(self, N):
+        """Emit the op list for batch N (host only, no GPU needed)."""
+        H, W = self.input_hw
+        pb = PlanBuilder(N)
+        inp = pb.new_buf(H, W, 3)                    # NHWC, channel-padded to 4
+        seq = list(self.backbone) if self.back_model else list(self.backbone1)
+        stem = seq[0]
+        # F.pad(x, (1, 2, 1, 2)) + 5x5 stride-2 conv + ReLU (blazeface.py:118-120,195)
+        x = pb.new_buf(H // 2, W // 2, 24)
+        pb.conv(inp.view(), npy(stem.weight), x.view(), stride=2, pad=(1, 1), bias=npy(stem.bias), act=L.ACT_RELU)
+        for blk in seq[2:]:
+            y = blk.emit(pb, x.view())
+            pb.free(x)
+            x = y
+        if self.back_model:
+            h = self.final.emit(pb, x.view())
+        else:
+            h = x
+            for blk in self.backbone2:
+                y = blk.emit(pb, h.view())
+                if h is not x:
+                    pb.free(h)
+                h = y
+        # heads: 1x1 convs written straight into the concatenated (b, 896, 16) / (b, 896, 1) tensors
+        # (blazeface.py:209-228: NHWC permute + reshape + cat are pure addressing here)
+        A = self.num_anchors
+        r_off, r_size = pb.new_raw(A * 16)
+        c_off, c_size = pb.new_raw(A)
+        def head(src, conv, off, per_img, skip_rows, row_floats):
+            cout = conv.weight.shape[0]
+            hb = Buf(src.H, src.W, cout, off + skip_rows * row_floats, 0, ns_=per_img)
+            pb.conv(src.view(), npy(conv.weight), View(hb, 0, cout), bias=npy(conv.bias))
+        head(x, self.classifier_8, c_off, A, 0, 1)
+        head(h, self.classifier_16, c_off, A, 512, 1)
+        head(x, self.regressor_8, r_off, A * 16, 0, 16)
+        head(h, self.regressor_16, r_off, A * 16, 512, 16)
+        return pb, inp, r_off, c_off
+
+    def _build(self, N):
+        A = self.num_anchors
+        pb, inp, r_off, c_off = self._emit(N)
+        plan = CompiledPlan(pb, self._device())
+        plan.inp = inp
+        plan.r = plan.arena[r_off: r_off + N * A * 16].view(N, A, 16)
+        plan.c = plan.arena[c_off: c_off + N * A].view(N, A, 1)
+        plan.input = plan.buf_tensor(inp, N)
+        return plan
+
+    def plan_for(self, N):
+        if N not in self._plans:
+            if self._device().type != "cuda":
+                raise L.FacepathError("BlazeFace runs only on a HIP device (model.to('cuda')); there is no CPU path")
+            self._plans[N] = self._build(N)
+        return self._plans[N]
+
+    # ------------------------------------------------------------------ inference
+    def forward(self, x):
+        """x: (b, 3, H, W) float, already in [-1, 1] (blazeface.py:192-228)."""
+        b = x.shape[0]
+        plan = self.plan_for(b)
+        plan.input[..., :3].copy_(x.to(self._device(), torch.float32).permute(0, 2, 3, 1))
+        plan.input[..., 3:].zero_()
+        plan.run()
+        return [plan.r, plan.c]
+
+    def _preprocess_lut(self):
+        # x.float() / 127.5 - 1.0 (blazeface.py:248-250), evaluated for the 256 u8 values in torch fp32
+        if getattr(self, "_lut", None) is None or self._lut.device != self._device():
+            self._lut = (torch.arange(256, dtype=torch.float32) / 127.5 - 1.0).to(self._device())
+        return self._lut
+
+    def predict_on_image(self, img):
+        if isinstance(img, np.ndarray):
+            img = torch.from_numpy(img.copy()).permute((2, 0, 1))
+        return self.predict_on_batch(img.unsqueeze(0))[0]
+
+    def raw_from_u8_nhwc(self, frames_u8):
+        """(b, H, W, 3) u8 RGB on device, H/W = the model input size -> raw (r, c) of the HIP plan."""
+        b, H, W, _ = frames_u8.shape
+        assert (H, W) == self.input_hw
+        plan = self.plan_for(b)
+        lib = L.load()
+        items = torch.tensor([[i, 0, 0, W, H, 0, 0, W, H] for i in range(b)], dtype=torch.int32,
+                             device=self._device())
+        L.check(lib.fp_resize_normalize(L.ptr(frames_u8), b, H, W, L.ptr(items), b, L.ptr(plan.input), H, W,
+                                        plan.input.shape[-1], L.ptr(self._preprocess_lut()), 0, 0,
+                                        L.current_stream(self._device())), "fp_resize_normalize")
+        plan.run()
+        return plan.r, plan.c
+
+    def predict_on_batch(self, x, use_numpy_for_post_proc=False):
+        """blazeface.py:266-319.  x: (b, H, W, 3) numpy u8 or (b, 3, H, W) tensor, RGB, model-input sized."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x).permute((0, 3, 1, 2))
+        assert x.shape[1] == 3
+        assert x.shape[2] == self.input_hw[0] and x.shape[3] == self.input_hw[1]
+        dev = self._device()
+        if x.dtype == torch.uint8:
+            r, c = self.raw_from_u8_nhwc(x.to(dev).permute(0, 2, 3, 1).contiguous())
+        else:
+            r, c = self.forward(x.to(dev).float() / 127.5 - 1.0)
+        dets, counts = self.postprocess(r, c)
+        counts = counts.cpu().tolist()
+        out = []
+        for i, k in enumerate(counts):
+            faces = dets[i, :k].clone() if k > 0 else torch.zeros((0, 17), device=dev)
+            out.append(faces.cpu().numpy() if use_numpy_for_post_proc else faces)
+        return out
+
+    def postprocess(self, r, c):
+        """decode + threshold + weighted NMS on device.  Returns (dets [b, 896, 17], counts [b])."""
+        assert self.anchors is not None, "call load_anchors()/set_anchors() first"
+        lib = L.load()
+        b, A = r.shape[0], self.num_anchors
+        dev = self._device()
+        s = L.current_stream(dev)
+        cand = torch.empty((b, A, 17), dtype=torch.float32, device=dev)
+        ccount = torch.empty((b,), dtype=torch.int32, device=dev)
+        L.check(lib.fp_blaze_decode(L.ptr(r), L.ptr(c), L.ptr(self.anchors), b, A, self.x_scale, self.y_scale,
+                                    self.w_scale, self.h_scale, self.score_clipping_thresh, self.min_score_thresh,
+                                    L.ptr(cand), L.ptr(ccount), s), "fp_blaze_decode")
+        out = torch.empty((b, A, 17), dtype=torch.float32, device=dev)
+        ocount = torch.empty((b,), dtype=torch.int32, device=dev)
+        L.check(lib.fp_blaze_weighted_nms(L.ptr(cand), L.ptr(ccount), b, A, self.min_suppression_threshold,
+                                          L.ptr(out), L.ptr(ocount), None, s), "fp_blaze_weighted_nms")
+        self._last_candidates = (cand, ccount)
+        return out, ocount

@@ -1,0 +1,201 @@
+"""Mobile-FaceNet on MI355X: the reference's classes and ``state_dict`` keys
+(face_detection_and_extraction/modules/mobile_facenet/mobile_facenet.py:39-154) with the forward pass
+compiled to a HIP plan.  BatchNorm stays an epilogue affine (x*s + b), as the reference keeps it un-folded;
+PReLU, the residual add and the final l2_norm are fused epilogues / one small kernel.
+"""
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ...plan import CompiledPlan, PlanBuilder, bn_affine
+from ..params import BNParams, ConvParams, LinearParams, PReLUParams, _NoCompute, npy
+
+
+def _affine(bn):
+    return bn_affine(npy(bn.weight), npy(bn.bias), npy(bn.running_mean), npy(bn.running_var), bn.eps)
+
+
+def l2_norm(input, axis=1):
+    """mobile_facenet.py:30-33 — kept for API compatibility on host tensors that are already embeddings;
+    inside the network the same formula is the FP_OP_L2NORM kernel."""
+    raise RuntimeError("l2_norm runs inside the HIP plan (FP_OP_L2NORM); call MobileFaceNet.forward")
+
+
+class Conv_block(_NoCompute):
+    """conv (no bias) -> BatchNorm2d -> PReLU (mobile_facenet.py:39-51)."""
+
+    def __init__(self, in_c, out_c, kernel=(1, 1), stride=(1, 1), padding=(0, 0), groups=1):
+        super().__init__()
+        self.k, self.s, self.p, self.groups = kernel[0], stride[0], padding[0], groups
+        self.in_c, self.out_c = in_c, out_c
+        self.conv = ConvParams(in_c, out_c, kernel[0], stride[0], padding[0], groups=groups, bias=False)
+        self.bn = BNParams(out_c)
+        self.prelu = PReLUParams(out_c)
+
+    def emit(self, pb, x, act=True):
+        OH = (x.H + 2 * self.p - self.k) // self.s + 1
+        OW = (x.W + 2 * self.p - self.k) // self.s + 1
+        y = pb.new_buf(OH, OW, self.out_c)
+        s, b = _affine(self.bn)
+        kw = dict(stride=self.s, pad=(self.p, self.p), scale=s, bias=b)
+        if act:
+            kw.update(slope=npy(self.prelu.weight), act=L.ACT_PRELU)
+        if self.groups == 1:
+            pb.conv(x, npy(self.conv.weight), y.view(), **kw)
+        else:
+            assert self.groups == self.in_c == self.out_c
+            pb.dwconv(x, npy(self.conv.weight), y.view(), **kw)
+        return y
+
+
+class Linear_block(_NoCompute):
+    """conv (no bias) -> BatchNorm2d (mobile_facenet.py:54-64)."""
+
+    def __init__(self, in_c, out_c, kernel=(1, 1), stride=(1, 1), padding=(0, 0), groups=1):
+        super().__init__()
+        self.k, self.s, self.p, self.groups = kernel[0], stride[0], padding[0], groups
+        self.in_c, self.out_c = in_c, out_c
+        self.conv = ConvParams(in_c, out_c, kernel[0], stride[0], padding[0], groups=groups, bias=False)
+        self.bn = BNParams(out_c)
+
+    def emit(self, pb, x, res=None):
+        OH = (x.H + 2 * self.p - self.k) // self.s + 1
+        OW = (x.W + 2 * self.p - self.k) // self.s + 1
+        y = pb.new_buf(OH, OW, self.out_c)
+        s, b = _affine(self.bn)
+        if self.groups == 1:
+            pb.conv(x, npy(self.conv.weight), y.view(), stride=self.s, pad=(self.p, self.p), scale=s, bias=b,
+                    res=res, res_mode=L.RES_ADD_AFTER_ACT if res is not None else L.RES_NONE)
+        else:
+            assert res is None
+            pb.dwconv(x, npy(self.conv.weight), y.view(), stride=self.s, pad=(self.p, self.p), scale=s, bias=b)
+        return y
+
+
+class Depth_Wise(_NoCompute):
+    """1x1 expand (PReLU) -> depthwise 3x3 stride s (PReLU) -> 1x1 project (BN only) [+ x]
+    (mobile_facenet.py:67-88)."""
+
+    def __init__(self, in_c, out_c, residual=False, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=1):
+        super().__init__()
+        self.conv = Conv_block(in_c, out_c=groups, kernel=(1, 1), padding=(0, 0), stride=(1, 1))
+        self.conv_dw = Conv_block(groups, groups, groups=groups, kernel=kernel, padding=padding, stride=stride)
+        self.project = Linear_block(groups, out_c, kernel=(1, 1), padding=(0, 0), stride=(1, 1))
+        self.residual = residual
+
+    def emit(self, pb, x):
+        a = self.conv.emit(pb, x)
+        b = self.conv_dw.emit(pb, a.view())
+        pb.free(a)
+        y = self.project.emit(pb, b.view(), res=x if self.residual else None)
+        pb.free(b)
+        return y
+
+
+class Residual(_NoCompute):
+    """num_block residual Depth_Wise blocks (mobile_facenet.py:91-101)."""
+
+    def __init__(self, c, num_block, groups, kernel=(3, 3), stride=(1, 1), padding=(1, 1)):
+        super().__init__()
+        self.model = nn.Sequential(*[Depth_Wise(c, c, residual=True, kernel=kernel, padding=padding, stride=stride,
+                                                groups=groups) for _ in range(num_block)])
+
+    def emit(self, pb, xbuf):
+        for blk in self.model:
+            y = blk.emit(pb, xbuf.view())
+            pb.free(xbuf)
+            xbuf = y
+        return xbuf
+
+
+class Flatten(_NoCompute):
+    pass
+
+
+class MobileFaceNet(nn.Module):
+    """mobile_facenet.py:104-154.  ``forward(x)``: (b, 3, 112, 112) float in [-1, 1] (BGR, as
+    mobile_facenet/utils.py:13-17 feeds it) -> (b, embedding_size) unit-norm embeddings."""
+
+    def __init__(self, embedding_size):
+        super().__init__()
+        self.embedding_size = embedding_size
+        self.conv1 = Conv_block(3, 64, kernel=(3, 3), stride=(2, 2), padding=(1, 1))
+        self.conv2_dw = Conv_block(64, 64, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=64)
+        self.conv_23 = Depth_Wise(64, 64, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=128)
+        self.conv_3 = Residual(64, num_block=4, groups=128, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+        self.conv_34 = Depth_Wise(64, 128, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=256)
+        self.conv_4 = Residual(128, num_block=6, groups=256, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+        self.conv_45 = Depth_Wise(128, 128, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=512)
+        self.conv_5 = Residual(128, num_block=2, groups=256, kernel=(3, 3), stride=(1, 1), padding=(1, 1))
+        self.conv_6_sep = Conv_block(128, 512, kernel=(1, 1), stride=(1, 1), padding=(0, 0))
+        self.conv_6_dw = Linear_block(512, 512, groups=512, kernel=(7, 7), stride=(1, 1), padding=(0, 0))
+        self.conv_6_flatten = Flatten()
+        self.linear = LinearParams(512, embedding_size, bias=False)
+        self.bn = BNParams(embedding_size)
+        self._plans = {}
+
+    def _device(self):
+        return self.linear.weight.device
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._plans = {}
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._plans = {}
+        return out
+
+    def _emit(self, N, H=112, W=112):
+        """Emit the op list for batch N (host only, no GPU needed)."""
+        pb = PlanBuilder(N)
+        inp = pb.new_buf(H, W, 3)
+        x = self.conv1.emit(pb, inp.view())
+        y = self.conv2_dw.emit(pb, x.view()); pb.free(x); x = y
+        y = self.conv_23.emit(pb, x.view()); pb.free(x); x = y
+        x = self.conv_3.emit(pb, x)
+        y = self.conv_34.emit(pb, x.view()); pb.free(x); x = y
+        x = self.conv_4.emit(pb, x)
+        y = self.conv_45.emit(pb, x.view()); pb.free(x); x = y
+        x = self.conv_5.emit(pb, x)
+        y = self.conv_6_sep.emit(pb, x.view()); pb.free(x); x = y
+        y = self.conv_6_dw.emit(pb, x.view()); pb.free(x); x = y        # (N, 1, 1, 512)
+        assert (x.H, x.W) == (1, 1), "Mobile-FaceNet expects 112x112 inputs (7x7 map before conv_6_dw)"
+        # Linear(512, E, bias=False) + BatchNorm1d as one 1x1 conv with an affine epilogue, then l2_norm
+        E = self.embedding_size
+        z = pb.new_buf(1, 1, E)
+        s, b = _affine(self.bn)
+        pb.conv(x.view(), npy(self.linear.weight).reshape(E, 512, 1, 1), z.view(0, E), scale=s, bias=b)
+        o = pb.new_buf(1, 1, E)
+        pb.l2norm(z.view(0, E), o.view(0, E))
+        return pb, inp, o
+
+    def _build(self, N):
+        E = self.embedding_size
+        pb, inp, o = self._emit(N)
+        plan = CompiledPlan(pb, self._device())
+        plan.input = plan.buf_tensor(inp, N)
+        plan.out = plan.buf_tensor(o, N).view(N, -1)[:, :E]
+        return plan
+
+    def plan_for(self, N):
+        if N not in self._plans:
+            if self._device().type != "cuda":
+                raise L.FacepathError("MobileFaceNet runs only on a HIP device (model.to('cuda')); there is no CPU path")
+            self._plans[N] = self._build(N)
+        return self._plans[N]
+
+    def forward(self, x):
+        b = x.shape[0]
+        plan = self.plan_for(b)
+        plan.input[..., :3].copy_(x.to(self._device(), torch.float32).permute(0, 2, 3, 1))
+        plan.input[..., 3:].zero_()
+        plan.run()
+        return plan.out
+
+    def embed_resident(self, n):
+        """Run the plan on whatever fp_resize_normalize wrote into plan_for(n).input; returns (n, E)."""
+        plan = self.plan_for(n)
+        plan.run()
+        return plan.out

@@ -1,0 +1,311 @@
+"""Plan builder: turns a network description into the flat ``fp_op`` array that
+``fp_plan_run`` (include/facepath.h) executes, plus the packed weight blob and
+the activation-arena layout.
+
+The host side mirrors the reference's module graph (modules/blazeface.py,
+modules/mobile_facenet.py, modules/yolov5_face.py emit ops in the order the
+reference's ``forward`` runs them); all arithmetic happens in the HIP kernels.
+Activations are NHWC fp32 inside one arena tensor; channel counts are padded
+to multiples of 4 (16-byte accesses) with zero weights in the padding.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def cpad(c):
+    """Internal channel count for a logical channel count (16-byte alignment)."""
+    return round_up(int(c), 4)
+
+
+@dataclass
+class Buf:
+    """An NHWC activation tensor inside the arena (offset in floats)."""
+    H: int
+    W: int
+    C: int       # physical channels = pixel stride
+    off: int
+    size: int    # floats, whole batch
+    ns_: int = -1   # per-image stride override (e.g. a head writing into a [B, 896, 16] tensor)
+
+    @property
+    def ld(self):
+        return self.C
+
+    @property
+    def ns(self):
+        return self.H * self.W * self.C if self.ns_ < 0 else self.ns_
+
+    def view(self, coff=0, C=None, cmul=1):
+        return View(self, coff, self.C - coff if C is None else C, cmul)
+
+
+@dataclass
+class View:
+    """Channel slice [coff, coff + C*cmul) of a Buf; cmul > 1 interleaves (channel_shuffle)."""
+    buf: Buf
+    coff: int
+    C: int
+    cmul: int = 1
+
+    @property
+    def H(self):
+        return self.buf.H
+
+    @property
+    def W(self):
+        return self.buf.W
+
+
+class Arena:
+    """First-fit free-list allocator over a float arena (offsets are multiples of 64 floats)."""
+
+    def __init__(self):
+        self.free = []   # sorted list of (off, size)
+        self.top = 0
+
+    def alloc(self, size):
+        size = round_up(size, 64)
+        for i, (off, sz) in enumerate(self.free):
+            if sz >= size:
+                if sz == size:
+                    self.free.pop(i)
+                else:
+                    self.free[i] = (off + size, sz - size)
+                return off, size
+        off = self.top
+        self.top += size
+        return off, size
+
+    def release(self, off, size):
+        self.free.append((off, size))
+        self.free.sort()
+        merged = []
+        for o, s in self.free:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        # a free block that ends at the top lowers the top
+        if merged and merged[-1][0] + merged[-1][1] == self.top:
+            self.top = merged[-1][0]
+            merged.pop()
+        self.free = merged
+
+
+def pack_conv_weight(w, cin_phys, cout_phys):
+    """[Cout, Cin, KH, KW] (torch OIHW) -> Wp[Kpad/4][Npad][4], k = (ky*KW + kx)*cin_phys + ci."""
+    w = np.asarray(w, dtype=np.float32)
+    cout, cin, kh, kw = w.shape
+    assert cin <= cin_phys and cout <= cout_phys
+    K = kh * kw * cin_phys
+    kpad = round_up(K, 8)
+    npad = round_up(cout_phys, 32)
+    full = np.zeros((kh, kw, cin_phys, npad), dtype=np.float32)
+    full[:, :, :cin, :cout] = np.transpose(w, (2, 3, 1, 0))
+    flat = np.zeros((kpad, npad), dtype=np.float32)
+    flat[:K] = full.reshape(K, npad)
+    return np.ascontiguousarray(flat.reshape(kpad // 4, 4, npad).transpose(0, 2, 1)).reshape(-1)
+
+
+def pack_dw_weight(w, c_phys):
+    """[C, 1, KH, KW] -> Wd[KH*KW][c_phys]."""
+    w = np.asarray(w, dtype=np.float32)
+    c, one, kh, kw = w.shape
+    assert one == 1 and c <= c_phys
+    out = np.zeros((kh * kw, c_phys), dtype=np.float32)
+    out[:, :c] = w.reshape(c, kh * kw).T
+    return out.reshape(-1)
+
+
+def pad_vec(v, n, fill=0.0):
+    v = np.asarray(v, dtype=np.float32).reshape(-1)
+    out = np.full((n,), fill, dtype=np.float32)
+    out[:v.shape[0]] = v
+    return out
+
+
+def bn_affine(gamma, beta, mean, var, eps):
+    """Eval-mode BatchNorm as y = x*s + b (mobile_facenet.py:48-49, common.py:50)."""
+    gamma, beta, mean, var = (np.asarray(t, dtype=np.float32) for t in (gamma, beta, mean, var))
+    s = gamma / np.sqrt(var + np.float32(eps))
+    return s.astype(np.float32), (beta - mean * s).astype(np.float32)
+
+
+class PlanBuilder:
+    def __init__(self, N):
+        self.N = int(N)
+        self.ops = []
+        self.wchunks = []
+        self.w_floats = 0
+        self.arena = Arena()
+        self.peak = 0
+
+    # ---- memory ----
+    def new_buf(self, H, W, C):
+        C = cpad(C)
+        off, size = self.arena.alloc(self.N * H * W * C)
+        self.peak = max(self.peak, self.arena.top)
+        return Buf(H, W, C, off, size)
+
+    def new_raw(self, floats_per_image):
+        """An untyped per-image region (heads / decoded tensors); returns (offset, size) in floats."""
+        off, size = self.arena.alloc(self.N * floats_per_image)
+        self.peak = max(self.peak, self.arena.top)
+        return off, size
+
+    def free(self, buf):
+        self.arena.release(buf.off, buf.size)
+
+    def add_weight(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self.w_floats
+        self.wchunks.append(arr)
+        pad = round_up(arr.size, 4) - arr.size   # keep every chunk 16-byte aligned
+        if pad:
+            self.wchunks.append(np.zeros(pad, dtype=np.float32))
+        self.w_floats += arr.size + pad
+        return off
+
+    # ---- op emission ----
+    def _base(self, kind, x, out, OH, OW):
+        op = L.FpOp()
+        op.kind = kind
+        op.N = self.N
+        op.H, op.W = x.H, x.W
+        op.OH, op.OW = OH, OW
+        op.Cin = x.C
+        op.in_ld = x.buf.ld
+        op.in_ns = x.buf.ns
+        op.in_off = x.buf.off + x.coff
+        op.out_ld = out.buf.ld
+        op.out_ns = out.buf.ns
+        op.out_off = out.buf.off + out.coff
+        op.out_cmul = out.cmul
+        op.KH = op.KW = 1
+        op.stride = 1
+        op.w_off = op.scale_off = op.bias_off = op.slope_off = -1
+        assert x.cmul == 1, "inputs must be dense channel slices"
+        assert out.H == OH and out.W == OW, (out.H, out.W, OH, OW)
+        return op
+
+    def conv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None,
+             act=L.ACT_NONE, res=None, res_mode=L.RES_NONE):
+        """Dense conv (OIHW weight); out is a View whose C >= Cout (extra channels get zeros)."""
+        cout, cin, kh, kw = w.shape
+        assert cin <= x.C, (cin, x.C)
+        OH, OW = out.H, out.W
+        op = self._base(L.OP_CONV, x, out, OH, OW)
+        op.Cout = out.C
+        op.KH, op.KW, op.stride = kh, kw, stride
+        op.pad_t, op.pad_l = pad
+        op.act, op.res_mode = act, res_mode
+        op.w_off = self.add_weight(pack_conv_weight(w, x.C, out.C))
+        if scale is not None:
+            op.scale_off = self.add_weight(pad_vec(scale, out.C, 0.0))
+        if bias is not None:
+            op.bias_off = self.add_weight(pad_vec(bias, out.C, 0.0))
+        if slope is not None:
+            op.slope_off = self.add_weight(pad_vec(slope, out.C, 0.0))
+        if res_mode != L.RES_NONE:
+            assert res is not None and res.cmul == 1
+            op.res_ld = res.buf.ld
+            op.res_ns = res.buf.ns
+            op.res_off = res.buf.off + res.coff
+            op.res_C = min(res.C, out.C)
+            op.res_H, op.res_W = res.H, res.W
+        self.ops.append(op)
+        return out
+
+    def dwconv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
+        c, _, kh, kw = w.shape
+        assert c <= x.C and out.C == x.C and out.cmul == 1
+        op = self._base(L.OP_DWCONV, x, out, out.H, out.W)
+        op.Cout = x.C
+        op.KH, op.KW, op.stride = kh, kw, stride
+        op.pad_t, op.pad_l = pad
+        op.act = act
+        op.w_off = self.add_weight(pack_dw_weight(w, x.C))
+        if scale is not None:
+            op.scale_off = self.add_weight(pad_vec(scale, x.C, 0.0))
+        if bias is not None:
+            op.bias_off = self.add_weight(pad_vec(bias, x.C, 0.0))
+        if slope is not None:
+            op.slope_off = self.add_weight(pad_vec(slope, x.C, 0.0))
+        self.ops.append(op)
+        return out
+
+    def maxpool(self, x, out, k, stride, pad):
+        assert out.C == x.C
+        op = self._base(L.OP_MAXPOOL, x, out, out.H, out.W)
+        op.Cout = x.C
+        op.KH = op.KW = k
+        op.stride = stride
+        op.pad_t = op.pad_l = pad
+        self.ops.append(op)
+        return out
+
+    def upsample2x(self, x, out):
+        assert out.C == x.C and out.H == 2 * x.H and out.W == 2 * x.W
+        op = self._base(L.OP_UPSAMPLE2X, x, out, out.H, out.W)
+        op.Cout = x.C
+        self.ops.append(op)
+        return out
+
+    def copy(self, x, out):
+        assert out.C == x.C and out.H == x.H and out.W == x.W
+        op = self._base(L.OP_COPY, x, out, out.H, out.W)
+        op.Cout = x.C
+        self.ops.append(op)
+        return out
+
+    def l2norm(self, x, out):
+        op = self._base(L.OP_L2NORM, x, out, out.H, out.W)
+        op.Cout = x.C
+        self.ops.append(op)
+        return out
+
+    def finish(self):
+        weights = np.concatenate(self.wchunks) if self.wchunks else np.zeros(4, np.float32)
+        return self.ops, weights, self.peak
+
+
+class CompiledPlan:
+    """Ops + device weights + arena, ready to run on a stream."""
+
+    def __init__(self, builder, device):
+        import torch
+        ops, weights, arena_floats = builder.finish()
+        self.n_ops = len(ops)
+        self.ops = (L.FpOp * max(self.n_ops, 1))(*ops)
+        self.device = torch.device(device)
+        self.weights = torch.from_numpy(weights).to(self.device)
+        self.arena_floats = int(arena_floats)
+        self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=self.device)
+        self.lib = L.load()
+        L.check(self.lib.fp_plan_validate(self.ops, self.n_ops, self.weights.numel(), self.arena_floats),
+                "fp_plan_validate")
+
+    def buf_tensor(self, buf, N):
+        """A torch view [N, H, W, C] of an arena buffer (no copy)."""
+        return self.arena[buf.off: buf.off + N * buf.ns].view(N, buf.H, buf.W, buf.C)
+
+    def run(self):
+        rc = self.lib.fp_plan_run(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
+                                  L.ptr(self.arena), self.arena_floats, L.current_stream(self.device))
+        L.check(rc, "fp_plan_run")
+
+
+def validate_on_host(builder):
+    """Host-only validation (no GPU): runs fp_plan_validate on the built ops."""
+    ops, weights, arena_floats = builder.finish()
+    arr = (L.FpOp * max(len(ops), 1))(*ops)
+    lib = L.load()
+    return lib.fp_plan_validate(arr, len(ops), int(weights.size), int(arena_floats))

@@ -1,0 +1,243 @@
+/*
+ * facepath.h — C ABI of libfacepath.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary for the detect -> embed -> similarity-filter hot path of
+ * SamSamhuns/face_detection_and_recognition.  The reference is 100 % Python and
+ * has no native boundary of its own; every entry point below
+ * therefore names the *Python* symbol of the reference whose arithmetic it
+ * replaces (paths relative to the reference root, fde = face_detection_and_extraction).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - Every pointer is a DEVICE pointer unless the parameter is documented "host".
+ *   - The caller owns every buffer (activations arena, weights, outputs).  The
+ *     library never allocates device memory and keeps no mutable global state.
+ *   - Stream-ordered: work is enqueued on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream) and the call returns without synchronising.
+ *   - Return value: FP_OK (0) or a negative fp_status; fp_strerror() gives text.
+ *   - Activations are NHWC fp32: element (n,y,x,c) of a view lives at
+ *     base + n*ns + (y*W + x)*ld + c   (ns, ld in floats).
+ */
+#ifndef FACEPATH_H
+#define FACEPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP_ABI_VERSION 1
+
+typedef enum fp_status {
+  FP_OK = 0,
+  FP_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, unsupported shape */
+  FP_ERR_BOUNDS = -2,        /* an op would touch memory outside the arena / weight blob */
+  FP_ERR_UNSUPPORTED = -3,   /* op kind / parameter combination not implemented */
+  FP_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after a launch */
+  FP_ERR_ALIGNMENT = -5      /* channel counts / strides / offsets not multiples of 4 floats where required */
+} fp_status;
+
+int fp_abi_version(void);
+const char* fp_strerror(int status);
+/* Last HIP error string seen by this thread's failing call ("" if none). */
+const char* fp_last_hip_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* 1. Network plans: one flat array of ops, executed back-to-back on a stream. */
+/* ------------------------------------------------------------------------- */
+
+enum fp_op_kind {
+  FP_OP_CONV = 1,       /* dense conv KHxKW (1x1 = pointwise GEMM), fp32 MFMA implicit GEMM */
+  FP_OP_DWCONV = 2,     /* depthwise conv KHxKW */
+  FP_OP_MAXPOOL = 3,    /* max pool, -inf padding, OH/OW given by caller (covers ceil_mode) */
+  FP_OP_UPSAMPLE2X = 4, /* nearest-neighbour 2x */
+  FP_OP_COPY = 5,       /* channel-slice copy (concat / chunk / shuffle interleave) */
+  FP_OP_L2NORM = 6,     /* out[m,:] = in[m,:] / ||in[m,:]||_2 over Cin channels (mobile_facenet.py:30-33) */
+  FP_OP_BLAZEBLOCK = 7  /* fused BlazeBlock: dw3x3 -> 1x1 -> (+shortcut) -> ReLU (blazeface.py:12-47) */
+};
+
+enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
+
+enum fp_res_mode {
+  FP_RES_NONE = 0,
+  FP_RES_ADD_BEFORE_ACT = 1, /* act(conv + res): BlazeBlock (blazeface.py:47) */
+  FP_RES_ADD_AFTER_ACT = 2,  /* res + act(conv): Depth_Wise residual (mobile_facenet.py:84-85), Bottleneck (common.py:87) */
+  FP_RES_POOL2_BEFORE_ACT = 3 /* res = maxpool2x2(input map) zero-padded on channels (blazeface.py:38-45) */
+};
+
+/*
+ * One op.  All *_off fields are offsets in FLOATS: in/out/res into the
+ * activation arena, w/scale/bias/slope into the weight blob (-1 = absent).
+ * Epilogue of CONV / DWCONV:  v = acc * scale[c] + bias[c]  (scale absent = 1,
+ * bias absent = 0), then residual/activation per res_mode/act; PReLU uses slope[c].
+ * Output element (n, oy, ox, c) is written at
+ *   out_off + n*out_ns + (oy*OW + ox)*out_ld + c*out_cmul        (out_cmul >= 1)
+ * Zero padding: taps that fall outside [0,H)x[0,W) read 0 (MAXPOOL: -inf), so
+ * asymmetric TFLite-style padding (blazeface.py:195, :38) is pad_t/pad_l plus OH/OW.
+ */
+typedef struct fp_op {
+  int32_t kind;
+  int32_t act;
+  int32_t res_mode;
+  int32_t N, H, W;        /* input batch / height / width */
+  int32_t OH, OW;         /* output height / width */
+  int32_t Cin, Cout;
+  int32_t KH, KW, stride;
+  int32_t pad_t, pad_l;
+  int32_t in_ld, out_ld, res_ld;   /* per-pixel stride (floats) */
+  int32_t out_cmul;                /* output channel multiplier (1 = dense, 2 = shuffle interleave) */
+  int32_t res_C;                   /* channels available in the residual; c >= res_C adds 0 */
+  int32_t res_H, res_W;            /* spatial dims of the residual map (POOL2: the un-pooled map) */
+  int64_t in_ns, out_ns, res_ns;   /* per-image stride (floats) */
+  int64_t in_off, out_off, res_off;
+  int64_t w_off, scale_off, bias_off, slope_off;
+} fp_op;
+
+/*
+ * Weight blob layouts (packed by the host side, see
+ * face_detection_and_recognition_amd/plan.py):
+ *   CONV   : Wp[Kpad/4][Npad][4]  with k = (ky*KW + kx)*Cin + ci, Kpad = roundup(KH*KW*Cin, 8),
+ *            Npad = roundup(Cout, 32); element (k, n) at ((k/4)*Npad + n)*4 + k%4; zero padded.
+ *   DWCONV : Wd[KH*KW][C]
+ *   scale / bias / slope : [Cout]
+ */
+
+/* Validates every op against arena_floats / weight_floats, then launches them in order. */
+int fp_plan_run(const fp_op* ops /*host*/, int n_ops,
+                const float* weights, size_t weight_floats,
+                float* arena, size_t arena_floats,
+                void* stream);
+
+/* Validation only (no GPU needed): same checks as fp_plan_run. */
+int fp_plan_validate(const fp_op* ops /*host*/, int n_ops, size_t weight_floats, size_t arena_floats);
+
+/* ------------------------------------------------------------------------- */
+/* 2. Image front end                                                          */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Bilinear u8 resize of a source rectangle into a destination rectangle of an
+ * fp32 NHWC canvas, then per-value LUT normalisation; pixels of the canvas
+ * outside the destination rectangle are set to lut[pad_value].
+ * Replaces: pad_resize_image (fde/modules/utils/image.py:31-59) + BGR->RGB
+ * (fde/modules/blazeface/model.py:75, y5/__init__.py:15) + normalisation
+ * (blazeface.py:248-250  x/127.5-1 ; y5/__init__.py:19-20  x/255 ;
+ *  mobile_facenet/utils.py:13  (x-127.5)/127.5) and the per-face crop + resize of
+ * extract_faces_from_dataset.py:289-303.  Resize arithmetic is OpenCV's
+ * INTER_LINEAR u8 fixed-point scheme (11-bit coefficients); cv2 is absent in
+ * the build container so this boundary is "parity unpinned" (DESIGN.md).
+ *
+ * rects: int32 [n_items][8] = {src_image, sx0, sy0, sw, sh, dx0, dy0, (unused)} followed by
+ * dst size dw, dh given by dst_w/dst_h of the resized region per item in rects[.][7]... see below.
+ */
+typedef struct fp_resize_item {
+  int32_t src_image;   /* index into frames */
+  int32_t sx, sy, sw, sh; /* source rectangle (pixels, inside the frame) */
+  int32_t dx, dy, dw, dh; /* destination rectangle inside the canvas */
+} fp_resize_item;
+
+int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int frame_w, /* [n,H,W,3] u8 */
+                        const fp_resize_item* items /*device*/, int n_items,
+                        float* canvas, int canvas_h, int canvas_w, int canvas_c /* >=3, extra channels zeroed */,
+                        const float* lut256 /*device, 256 floats*/, int pad_value, int swap_rb,
+                        void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* 3. BlazeFace post-processing                                                */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * _tensors_to_detections + _decode_boxes (blazeface.py:321-402): clamp +-clip,
+ * sigmoid, score >= min_score_thresh, anchor decode.  Candidates are compacted
+ * per image in anchor order into cand[B][num_anchors][17] / cand_count[B].
+ */
+int fp_blaze_decode(const float* raw_boxes /*[B,A,16]*/, const float* raw_scores /*[B,A]*/,
+                    const float* anchors /*[A,4]*/, int B, int A,
+                    float x_scale, float y_scale, float w_scale, float h_scale,
+                    float score_clip, float min_score_thresh,
+                    float* cand /*[B,A,17]*/, int32_t* cand_count /*[B]*/, void* stream);
+
+/*
+ * _weighted_non_max_suppression (blazeface.py:404-458) + overlap_similarity
+ * (:463-526) for a batch: one workgroup per image.  dets [B][max_in][17] with
+ * counts[B]; out [B][max_in][17], out_count[B]; member_of [B][max_in] (optional,
+ * may be NULL) receives, per INPUT detection, the index of the output cluster it
+ * was blended into (the bit-exact parity object).  Ties in score are ordered by
+ * input index (stable).  A box whose self-IoU is not > thr (degenerate, SURVEY F8:
+ * the reference never terminates) is emitted alone and removed.
+ */
+int fp_blaze_weighted_nms(const float* dets, const int32_t* counts, int B, int max_in,
+                          float iou_thresh, float* out, int32_t* out_count, int32_t* member_of,
+                          void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* 4. YOLOv5-face post-processing                                              */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Detect.forward inference decode (y5/models/yolo.py:62-108): heads are the raw
+ * 1x1-conv outputs in NHWC [B,ny,nx,na*16]; out is [B, sum(na*ny*nx), 16] in the
+ * reference's (level, anchor, y, x) order.
+ */
+int fp_yolo_decode(const float* head, int B, int ny, int nx, int na,
+                   float stride, const float* anchors_px /*host [na][2]*/,
+                   float* out, int64_t out_image_stride /*floats*/, int64_t out_row_offset /*rows*/,
+                   void* stream);
+
+/*
+ * non_max_suppression_face (y5/utils/general.py:370-453), nc = 1: obj > conf,
+ * conf = obj*cls > conf, xywh->xyxy, torchvision.ops.nms(iou) semantics
+ * (greedy, IoU = inter/(a+b-inter), suppress IoU > thr, score-descending, ties by index).
+ * pred [B][n_rows][16]; out [B][max_out][16] rows = (x1,y1,x2,y2,conf,lmk[10],cls);
+ * out_count[B]; keep_idx [B][max_out] = row index into pred (bit-exact parity object);
+ * overflow[B] is set to 1 when an image had more than max_cand candidates
+ * (the host raises; the reference has no cap).
+ */
+int fp_yolo_nms(const float* pred, int B, int n_rows, float conf_thres, float iou_thres,
+                int max_cand, int max_out,
+                float* out, int32_t* out_count, int32_t* keep_idx, int32_t* overflow,
+                void* scratch, size_t scratch_bytes, void* stream);
+size_t fp_yolo_nms_scratch_bytes(int B, int max_cand);
+
+/*
+ * w_non_max_suppression (fde/modules/yolov5_face/onnx/onnx_utils.py:107-163), num_classes=1:
+ * obj >= conf, +1-pixel IoU (:76-104), keep iou < nms_thres.  out rows = (x1,y1,x2,y2,obj,cls_conf,cls).
+ */
+int fp_yolo_w_nms(const float* pred, int B, int n_rows, float conf_thres, float nms_thres,
+                  int max_cand, int max_out,
+                  float* out /*[B][max_out][7]*/, int32_t* out_count, int32_t* keep_idx, int32_t* overflow,
+                  void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* 5. Similarity filter                                                        */
+/* ------------------------------------------------------------------------- */
+
+/* inv_norm[m] = 1/||x[m,:]||  (cosine: extract_and_label_faces_from_dataset.py:106) */
+int fp_row_inv_norm(const float* x, int64_t M, int D, float* inv_norm, void* stream);
+
+/*
+ * Cosine filter: for each gallery row g: best = max_j <g, r_j> * ginv[g] * rinv[j],
+ * arg = the smallest j attaining it, keep = best >= tau.  S is never materialised.
+ * packed is a caller-provided [M] uint64 scratch.
+ */
+int fp_cosine_filter(const float* G, const float* ginv, int64_t M,
+                     const float* R, const float* rinv, int Nr, int D, float tau,
+                     float* best, int32_t* arg, uint8_t* keep,
+                     uint64_t* packed, void* stream);
+
+/*
+ * get_ref_mean_vec_and_thres_from_imgs (sff/filter_faces_using_reference.py:71-100):
+ * mean over the R reference rows, thres = max_i ||mean - f_i||_2.  out_mean [D], out_thres [1].
+ */
+int fp_l2_mean_thres(const float* ref, int R, int D, float* out_mean, float* out_thres, void* stream);
+
+/* filter loop (sff/filter_faces_using_reference.py:183-197): dist = ||e - mean||_2 ; keep = dist <= thres. */
+int fp_l2_filter(const float* E, int64_t M, int D, const float* mean, const float* thres /*device [1]*/,
+                 float* dist, uint8_t* keep, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACEPATH_H */

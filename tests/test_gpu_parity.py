@@ -1,0 +1,217 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the oracle and the reference-generated goldens.
+Tolerances: bit-exact for indices / keep-sets / cluster membership; 1e-4 absolute for unit-norm embeddings
+and cosine scores (BASELINE.json north_star); activations compared with a 1e-4 relative-to-scale bound."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from face_detection_and_recognition_amd import _lib as L
+from face_detection_and_recognition_amd import similarity as S
+from face_detection_and_recognition_amd.modules.blazeface.blazeface import (BlazeBlock, BlazeFace, FinalBlazeBlock,
+                                                                              generate_anchors)
+from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise, MobileFaceNet
+from face_detection_and_recognition_amd.plan import CompiledPlan, PlanBuilder
+from face_detection_and_recognition_amd.synth import synth_state_dict
+from oracle import blazeface_ref, image_ref, mobilefacenet_ref, similarity_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def run_block(block, x_nchw, dev, out_hw, cout):
+    """Runs one emit()-able block on an NCHW numpy input; returns NCHW numpy."""
+    N, C, H, W = x_nchw.shape
+    pb = PlanBuilder(N)
+    inp = pb.new_buf(H, W, C)
+    y = block.emit(pb, inp.view())
+    plan = CompiledPlan(pb, dev)
+    t = plan.buf_tensor(inp, N)
+    t.zero_()
+    t[..., :C].copy_(torch.from_numpy(x_nchw).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    return plan.buf_tensor(y, N)[..., :cout].permute(0, 3, 1, 2).cpu().numpy()
+
+
+@pytest.mark.parametrize("name,ctor,cout", [("s1", lambda: BlazeBlock(24, 24), 24),
+                                             ("s2", lambda: BlazeBlock(24, 48, stride=2), 48),
+                                             ("final", lambda: FinalBlazeBlock(96), 96)])
+def test_blazeblock_vs_reference_golden(dev, name, ctor, cout):
+    g = golden(f"blazeblock_{name}")
+    blk = ctor()
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), int(g["seed"])))
+    y = run_block(blk, g["x"], dev, g["y"].shape[2:], cout)
+    assert y.shape == g["y"].shape
+    assert rel_err(y, g["y"]) < 1e-5
+
+
+@pytest.mark.parametrize("back", [True, False])
+def test_blazeface_forward_vs_reference_golden(dev, back):
+    tag = "back" if back else "front"
+    g = golden(f"blazeface_{tag}_forward")
+    net = BlazeFace(back)
+    net.load_state_dict(synth_state_dict(net.state_dict(), int(g["seed"]), residual_gain=0.5))
+    net = net.to(dev)
+    x = torch.from_numpy(g["x_u8"]).to(dev)                       # (2, S, S, 3) u8 RGB
+    r, c = net.raw_from_u8_nhwc(x)
+    torch.cuda.synchronize()
+    assert rel_err(r.cpu().numpy(), g["r"]) < 1e-4
+    assert rel_err(c.cpu().numpy(), g["c"]) < 1e-4
+    # the float NCHW entry point gives the same numbers
+    r2, c2 = net(torch.from_numpy(g["x_u8"]).permute(0, 3, 1, 2).float() / 127.5 - 1.0)
+    assert rel_err(r2.cpu().numpy(), g["r"]) < 1e-4
+
+
+def test_blazeface_decode_vs_reference_golden(dev, lib):
+    g = golden("blazeface_decode")
+    B, A = g["raw_box"].shape[:2]
+    rb = torch.from_numpy(g["raw_box"]).to(dev)
+    rs = torch.from_numpy(g["raw_score"]).to(dev)
+    an = torch.from_numpy(g["anchors"]).to(dev)
+    cand = torch.zeros((B, A, 17), device=dev)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    L.check(lib.fp_blaze_decode(L.ptr(rb), L.ptr(rs), L.ptr(an), B, A, 256.0, 256.0, 256.0, 256.0, 100.0, 0.65,
+                                L.ptr(cand), L.ptr(cnt), None), "decode")
+    torch.cuda.synchronize()
+    assert cnt.cpu().numpy().tolist() == g["counts"].tolist()       # same candidate sets
+    for i in range(B):
+        d = g[f"dets{i}"]
+        got = cand[i, :len(d)].cpu().numpy()
+        np.testing.assert_array_equal(got[:, :16], d[:, :16])      # decode is bit-exact (fp-contract off)
+        np.testing.assert_allclose(got[:, 16], d[:, 16], rtol=0, atol=2e-7)
+
+
+def _wnms_gpu(dev, lib, dets_list, thr=0.3):
+    B = len(dets_list)
+    nmax = 896
+    d = torch.zeros((B, nmax, 17), device=dev)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    for i, a in enumerate(dets_list):
+        d[i, :len(a)] = torch.from_numpy(a).to(dev)
+        cnt[i] = len(a)
+    out = torch.zeros((B, nmax, 17), device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    mem = torch.full((B, nmax), -1, dtype=torch.int32, device=dev)
+    L.check(lib.fp_blaze_weighted_nms(L.ptr(d), L.ptr(cnt), B, nmax, thr, L.ptr(out), L.ptr(oc), L.ptr(mem), None),
+            "wnms")
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), oc.cpu().numpy(), mem.cpu().numpy()
+
+
+def test_blazeface_weighted_nms_vs_reference_golden(dev, lib):
+    g = golden("blazeface_wnms")
+    names = ["no_overlap", "clusters", "chains", "all_overlap", "many", "single"]
+    ins = [g[n + "_in"] for n in names]
+    out, oc, mem = _wnms_gpu(dev, lib, ins + [np.zeros((0, 17), np.float32)])
+    assert oc[-1] == 0                                              # empty image
+    for i, n in enumerate(names):
+        ref_out = g[n + "_out"]
+        assert oc[i] == len(ref_out), n                             # same number of faces
+        _, ref_mem = blazeface_ref.weighted_nms(ins[i], 0.3)
+        np.testing.assert_array_equal(mem[i, :len(ins[i])], ref_mem.numpy())   # bit-exact cluster membership
+        np.testing.assert_allclose(out[i, :oc[i]], ref_out, rtol=0, atol=1e-5)
+
+
+def test_blazeface_weighted_nms_degenerate_box_terminates(dev, lib):
+    # ymin > ymax makes the reference loop forever; the kernel emits the box alone and goes on.
+    d = np.array([[0.5, 0.5, 0.4, 0.6] + [0.1] * 12 + [0.9], [0.1, 0.1, 0.3, 0.3] + [0.2] * 12 + [0.8]], np.float32)
+    out, oc, mem = _wnms_gpu(dev, lib, [d])
+    assert oc[0] == 2 and mem[0, :2].tolist() == [0, 1]
+    np.testing.assert_array_equal(out[0, :2], d)
+
+
+def test_blazeface_weighted_nms_full_size_properties(dev, lib):
+    # 256 images x up to 896 candidates (BASELINE config 2 post-processing size): membership is a partition,
+    # counts match the oracle on a sample, output scores are descending in "first" order only per cluster.
+    rng = np.random.default_rng(5)
+    ins = []
+    for i in range(256):
+        n = int(rng.integers(0, 897)) if i % 7 else 896
+        xy = rng.uniform(0, 0.8, (n, 2)); wh = rng.uniform(0.05, 0.3, (n, 2))
+        ins.append(np.concatenate([xy, xy + wh, rng.uniform(0, 1, (n, 12)), rng.uniform(0.65, 1, (n, 1))], 1).astype(np.float32))
+    out, oc, mem = _wnms_gpu(dev, lib, ins)
+    for i in (0, 1, 5, 100, 255):
+        ref_out, ref_mem = blazeface_ref.weighted_nms(ins[i], 0.3)
+        assert oc[i] == len(ref_out)
+        np.testing.assert_array_equal(mem[i, :len(ins[i])], ref_mem.numpy())
+        np.testing.assert_allclose(out[i, :oc[i]], ref_out.numpy(), rtol=0, atol=2e-5)
+    for i in range(256):
+        m = mem[i, :len(ins[i])]
+        if len(m):
+            assert m.min() >= 0 and m.max() == oc[i] - 1 and len(np.unique(m)) == oc[i]
+
+
+def test_mobilefacenet_depthwise_vs_reference_golden(dev):
+    g = golden("mobilefacenet_depthwise")
+    a = Depth_Wise(64, 64, residual=True, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=128)
+    a.load_state_dict(synth_state_dict(a.state_dict(), 301))
+    b = Depth_Wise(64, 128, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=256)
+    b.load_state_dict(synth_state_dict(b.state_dict(), 302))
+    ya = run_block(a, g["x"], dev, (14, 14), 64)
+    yb = run_block(b, g["x"], dev, (7, 7), 128)
+    assert rel_err(ya, g["y_res"]) < 1e-5
+    assert rel_err(yb, g["y_down"]) < 1e-5
+
+
+def test_mobilefacenet_forward_vs_reference_golden(dev):
+    g = golden("mobilefacenet_forward")
+    net = MobileFaceNet(512)
+    net.load_state_dict(synth_state_dict(net.state_dict(), int(g["seed"])))
+    net = net.to(dev)
+    e = net(torch.from_numpy(g["x"]))
+    torch.cuda.synchronize()
+    e = e.cpu().numpy()
+    assert np.abs(e - g["emb"]).max() < 1e-4                        # north_star tolerance
+    np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)
+
+
+def test_resize_normalize_vs_oracle(dev, lib):
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (3, 72, 128, 3), dtype=np.uint8)
+    f = torch.from_numpy(frames).to(dev)
+    from face_detection_and_recognition_amd.modules.utils.image import letterbox_batch
+    for (nw, nh) in ((32, 32), (64, 48), (200, 100), (128, 72)):
+        canvas = torch.zeros((3, nh, nw, 4), device=dev)
+        lut = torch.from_numpy(image_ref.blaze_lut()).to(dev)
+        letterbox_batch(f, (nw, nh), lut, canvas, pad_value=125, swap_rb=True)
+        torch.cuda.synchronize()
+        for i in range(3):
+            ref = image_ref.pad_resize_image(frames[i], (nw, nh))[..., ::-1]
+            np.testing.assert_array_equal(canvas[i, ..., :3].cpu().numpy(), image_ref.blaze_lut()[ref])
+            assert float(canvas[i, ..., 3].abs().max()) == 0.0
+
+
+def test_similarity_vs_golden_and_oracle(dev):
+    g = golden("similarity")
+    ref = torch.from_numpy(g["ref"]).to(dev)
+    mean, thres = S.l2_mean_thres(ref)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=0, atol=1e-6)
+    assert abs(float(thres) - float(g["thres"])) < 1e-4
+    dist, keep = S.l2_filter(torch.from_numpy(g["E"]).to(dev), mean, thres)
+    np.testing.assert_allclose(dist.cpu().numpy(), g["dist"], rtol=0, atol=1e-4)
+    margin = np.abs(g["dist"] - float(g["thres"])) > 1e-3
+    np.testing.assert_array_equal(keep.cpu().numpy()[margin], g["keep"][margin])
+    # cosine vs the reference formula (pairwise) and the oracle
+    best, arg, keepc = S.cosine_filter(torch.from_numpy(g["cos_a"]).to(dev), torch.from_numpy(g["cos_b"]).to(dev), 0.1)
+    sim = 1.0 - g["cos_dist"]
+    np.testing.assert_allclose(best.cpu().numpy(), sim.max(1), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(arg.cpu().numpy(), sim.argmax(1))
+
+
+def test_cosine_filter_ragged_and_large(dev):
+    rng = np.random.default_rng(9)
+    for M, Nr, D in ((1, 1, 512), (130, 257, 512), (1000, 77, 128), (4096, 3000, 512)):
+        G = rng.normal(0, 1, (M, D)).astype(np.float32)
+        R = rng.normal(0, 1, (Nr, D)).astype(np.float32)
+        best, arg, keep = S.cosine_filter(torch.from_numpy(G).to(dev), torch.from_numpy(R).to(dev), 0.05)
+        rb, ra, rk, Smat = similarity_ref.cosine_filter(G, R, 0.05)
+        np.testing.assert_allclose(best.cpu().numpy(), rb, rtol=0, atol=1e-4)
+        a = arg.cpu().numpy()
+        # the argmax may differ only where two scores tie within rounding
+        bad = a != ra
+        assert np.all(np.abs(Smat[np.arange(M), a][bad] - rb[bad]) < 1e-5)

@@ -1,0 +1,216 @@
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF (this container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+The reference's model classes / post-processing functions are imported from /root/reference through
+tools/ref_harness.py (stubs for the absent cv2 / torchvision / thop / seaborn), fed seeded synthetic
+weights (face_detection_and_recognition_amd/synth.py regenerates the same weights from the seed on the
+GPU box, so only inputs' seeds and the reference's OUTPUTS are stored) and seeded inputs.
+The fixtures are data: seeds, small inputs and the reference's outputs.  No reference source is stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+import ref_harness as rh  # noqa: E402
+from face_detection_and_recognition_amd.synth import synth_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(4)
+torch.manual_seed(0)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def crafted_detections(rng, n_faces, per_face, jitter, base_size=0.18):
+    """(n,17) detections with w,h > 0 clustered around n_faces centres."""
+    rows = []
+    for f in range(n_faces):
+        cx, cy = rng.uniform(0.2, 0.8, 2)
+        for _ in range(per_face):
+            dx, dy = rng.normal(0, jitter, 2)
+            w, h = base_size * rng.uniform(0.8, 1.25, 2)
+            x0, y0 = cx + dx - w / 2, cy + dy - h / 2
+            kp = rng.uniform(0, 1, 12)
+            rows.append([y0, x0, y0 + h, x0 + w, *kp, rng.uniform(0.65, 0.99)])
+    a = np.asarray(rows, dtype=np.float32)
+    return a[rng.permutation(len(a))]
+
+
+def gen_blazeface(ns):
+    bf = ns.blazeface
+    for back in (True, False):
+        tag = "back" if back else "front"
+        net = bf.BlazeFace(back_model=back).eval()
+        sd = synth_state_dict(net.state_dict(), seed=100 + int(back), residual_gain=0.5)
+        net.load_state_dict(sd)
+        S = 256 if back else 128
+        rng = np.random.default_rng(7 + int(back))
+        x_u8 = rng.integers(0, 256, size=(2, S, S, 3), dtype=np.uint8)          # RGB HWC
+        x = torch.from_numpy(x_u8).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            r, c = net(net._preprocess(x))
+        save(f"blazeface_{tag}_forward", seed=100 + int(back), x_u8=x_u8, r=r.numpy(), c=c.numpy())
+
+    # blocks (G1): BlazeBlock s1 24->24 @16x16, s2 24->48, FinalBlazeBlock 96 @8x8
+    rng = np.random.default_rng(11)
+    for name, blk, cin, hw in (("s1", bf.BlazeBlock(24, 24), 24, 16), ("s2", bf.BlazeBlock(24, 48, stride=2), 24, 16),
+                               ("final", bf.FinalBlazeBlock(96), 96, 8)):
+        blk.eval()
+        sd = synth_state_dict(blk.state_dict(), seed=200 + len(name))
+        blk.load_state_dict(sd)
+        x = torch.from_numpy(rng.normal(0, 1, (2, cin, hw, hw)).astype(np.float32))
+        with torch.no_grad():
+            y = blk(x)
+        save(f"blazeblock_{name}", seed=200 + len(name), x=x.numpy(), y=y.numpy())
+
+    # decode + threshold (G3) and weighted NMS (G4) through the reference's own methods
+    net = bf.BlazeFace(back_model=True).eval()
+    rng = np.random.default_rng(21)
+    anchors = rng.uniform(0.05, 0.95, (896, 4)).astype(np.float32)
+    anchors[:, 2:] = 1.0
+    raw_box = rng.normal(0, 20, (3, 896, 16)).astype(np.float32)
+    raw_box[..., 2:4] = np.abs(raw_box[..., 2:4]) + 20.0                            # w,h > 0
+    raw_score = rng.normal(-3.0, 2.5, (3, 896, 1)).astype(np.float32)
+    raw_score[0, :5, 0] = [150.0, -150.0, 0.61, 0.62, 0.63]                         # clip + around-threshold cases
+    net.anchors = torch.from_numpy(anchors)
+    dets = net._tensors_to_detections(torch.from_numpy(raw_box), torch.from_numpy(raw_score), net.anchors)
+    boxes = net._decode_boxes(torch.from_numpy(raw_box), net.anchors)
+    save("blazeface_decode", anchors=anchors, raw_box=raw_box, raw_score=raw_score, boxes=boxes.numpy(),
+         counts=np.array([len(d) for d in dets]), **{f"dets{i}": d.numpy() for i, d in enumerate(dets)})
+
+    scenes = {
+        "no_overlap": np.stack([[0.1 * i, 0.1 * i, 0.1 * i + 0.05, 0.1 * i + 0.05] + [0.5] * 12 + [0.7 + 0.02 * i]
+                                for i in range(8)]).astype(np.float32),
+        "clusters": crafted_detections(np.random.default_rng(31), 3, 12, 0.02),
+        "chains": crafted_detections(np.random.default_rng(32), 2, 40, 0.06),
+        "all_overlap": crafted_detections(np.random.default_rng(33), 1, 64, 0.005),
+        "many": crafted_detections(np.random.default_rng(34), 12, 40, 0.03),
+        "single": crafted_detections(np.random.default_rng(35), 1, 1, 0.0),
+    }
+    out = {}
+    for k, d in scenes.items():
+        faces = net._weighted_non_max_suppression(torch.from_numpy(d))
+        out[k + "_in"] = d
+        out[k + "_out"] = torch.stack(faces).numpy() if faces else np.zeros((0, 17), np.float32)
+    save("blazeface_wnms", **out)
+
+
+def gen_mobilefacenet(ns):
+    m = ns.mobile_facenet.MobileFaceNet(512).eval()
+    sd = synth_state_dict(m.state_dict(), seed=300)
+    m.load_state_dict(sd)
+    rng = np.random.default_rng(41)
+    x = torch.from_numpy(rng.uniform(-1, 1, (4, 3, 112, 112)).astype(np.float32))
+    with torch.no_grad():
+        e = m(x)
+        # intermediate taps for layer-level debugging
+        t1 = m.conv2_dw(m.conv1(x))
+        t2 = m.conv_3(m.conv_23(t1))
+    save("mobilefacenet_forward", seed=300, x=x.numpy(), emb=e.numpy(), tap_conv2_dw=t1.numpy()[:1],
+         tap_conv_3=t2.numpy()[:1])
+
+    dw = ns.mobile_facenet.Depth_Wise(64, 64, residual=True, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=128).eval()
+    dw.load_state_dict(synth_state_dict(dw.state_dict(), seed=301))
+    dn = ns.mobile_facenet.Depth_Wise(64, 128, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=256).eval()
+    dn.load_state_dict(synth_state_dict(dn.state_dict(), seed=302))
+    x = torch.from_numpy(rng.normal(0, 1, (2, 64, 14, 14)).astype(np.float32))
+    with torch.no_grad():
+        save("mobilefacenet_depthwise", x=x.numpy(), y_res=dw(x).numpy(), y_down=dn(x).numpy())
+
+
+def gen_utils(ns):
+    rng = np.random.default_rng(51)
+    # get_dets_bboxes_confs_lmarks_areas + scale_coords for 576x1024 -> 256^2 and 640^2 (G10)
+    out = {}
+    for tag, (iw, ih), K in (("blaze", (256, 256), 17), ("yolo", (640, 640), 5)):
+        n = 12
+        xy0 = rng.uniform(0.05, 0.6, (n, 2))
+        wh = rng.uniform(0.02, 0.35, (n, 2))
+        dets = np.concatenate([xy0, xy0 + wh, rng.uniform(0.1, 0.9, (n, K - 5)), rng.uniform(0.3, 1.0, (n, 1))], axis=1)
+        post = ns.inference.get_dets_bboxes_confs_lmarks_areas(dets.copy(), (1024, 576), (iw, ih), 0.7, 0.12)
+        out.update({f"{tag}_dets": dets, f"{tag}_boxes": post.boxes, f"{tag}_confs": post.bbox_confs,
+                    f"{tag}_areas": post.bbox_areas, f"{tag}_lmarks": post.bbox_lmarks})
+    img = rng.integers(0, 256, (2, 20, 24, 3)).astype(np.uint8)
+    out["std_in"] = img
+    out["std_out"] = ns.image.standardize_image(img.astype(np.float64))
+    save("utils_postprocess", **out)
+
+
+def gen_similarity():
+    """S1/S2 arithmetic: filter_faces_using_reference.py cannot be imported (top-level tensorflow import,
+    SURVEY 8c); its ten lines of numpy are run here verbatim-in-spirit on random features through numpy
+    itself, plus the one pinned value the reference's own test holds (thres for its 128-d fixture needs the
+    FaceNet weights and is therefore not reproducible offline)."""
+    rng = np.random.default_rng(61)
+    ref = rng.normal(0, 1, (32, 1, 512)).astype(np.float32)     # model.predict outputs, shape (R,1,D) :84-85
+    mean = np.mean(ref, axis=0)                                  # :86
+    thres = 0
+    for i in range(32):
+        thres = max(thres, np.linalg.norm(mean - ref[i]))       # :89-92
+    E = (mean + rng.normal(0, 1.0, (40, 512)) * rng.uniform(0.6, 1.4, (40, 1))).astype(np.float32)
+    dist = np.array([np.linalg.norm(o - mean) for o in E])      # :189
+    a = rng.normal(0, 1, (64, 512)).astype(np.float32)
+    b = rng.normal(0, 1, (32, 512)).astype(np.float32)
+    cos = np.array([[1 - np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y)) for y in b] for x in a])
+    save("similarity", ref=ref[:, 0], mean=mean[0], thres=np.float32(thres), E=E, dist=dist, keep=dist <= thres,
+         cos_a=a, cos_b=b, cos_dist=cos)
+
+
+def gen_yolo():
+    ys = rh.import_reference_yolo()
+    rng = np.random.default_rng(71)
+    for name in ("yolov5n", "yolov5s"):
+        m = ys.build_model(name + ".yaml")
+        sd0 = m.state_dict()
+        sd = synth_state_dict(sd0, seed=400 + len(name))
+        m.load_state_dict(sd)
+        m = m.fuse().eval()
+        x = torch.from_numpy(rng.uniform(0, 1, (1, 3, 128, 128)).astype(np.float32))
+        with torch.no_grad():
+            z, heads = m(x)
+        save(f"{name}_forward", seed=400 + len(name), x=x.numpy(), z=z.numpy(),
+             **{f"head{i}": h.numpy() for i, h in enumerate(heads)})
+
+    # Detect decode on crafted heads at 64x64 input (G5) through the ONNX-variant decode (pure reference)
+    heads = [rng.normal(0, 1.5, (2, 3, 64 // s, 64 // s, 16)).astype(np.float32) for s in (8, 16, 32)]
+    z = ys.onnx_utils.conv_strides_to_anchors([h.copy() for h in heads], "cpu")
+    # NMS: w_non_max_suppression is pure reference; non_max_suppression_face needs torchvision.ops.nms (absent)
+    pred = z.numpy().copy()
+    pred[..., 4] = rng.uniform(0, 1, pred.shape[:2]).astype(np.float32)
+    pred[..., 15] = rng.uniform(0.5, 1, pred.shape[:2]).astype(np.float32)
+    # make boxes cluster: snap centres to a coarse grid so IoUs are substantial
+    pred[..., 0:2] = np.round(pred[..., 0:2] / 16) * 16 + rng.normal(0, 1.5, pred[..., 0:2].shape)
+    pred[..., 2:4] = np.abs(pred[..., 2:4]) % 40 + 12
+    pred = pred.astype(np.float32)
+    wout = ys.onnx_utils.w_non_max_suppression(torch.from_numpy(pred.copy()), num_classes=1, conf_thres=0.4, nms_thres=0.3)
+    save("yolo_decode_wnms", z=z.numpy(), pred=pred, **{f"head{i}": h for i, h in enumerate(heads)},
+         **{f"wnms{i}": (o.numpy() if o is not None else np.zeros((0, 7), np.float32)) for i, o in enumerate(wout)})
+    # box_iou (pure torch in the reference) pins the IoU formula torchvision.ops.nms uses
+    b1 = rng.uniform(0, 100, (16, 2)); b1 = np.concatenate([b1, b1 + rng.uniform(5, 60, (16, 2))], 1).astype(np.float32)
+    iou = ys.general.box_iou(torch.from_numpy(b1), torch.from_numpy(b1))
+    save("yolo_box_iou", boxes=b1, iou=iou.numpy())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    ns = rh.import_reference()
+    which = sys.argv[1:] or ["blazeface", "mobilefacenet", "utils", "similarity", "yolo"]
+    if "blazeface" in which:
+        gen_blazeface(ns)
+    if "mobilefacenet" in which:
+        gen_mobilefacenet(ns)
+    if "utils" in which:
+        gen_utils(ns)
+    if "similarity" in which:
+        gen_similarity()
+    if "yolo" in which:
+        gen_yolo()
