@@ -57,7 +57,13 @@ SIGNATURES = {
     "fp_last_hip_error": (C.c_char_p, []),
     "fp_plan_run": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P]),
     "fp_plan_validate": (_I, [C.POINTER(FpOp), _I, _SZ, _SZ]),
+    "fp_timer_create": (_I, [_I, C.POINTER(_P)]),
+    "fp_timer_destroy": (None, [_P]),
+    "fp_plan_run_timed": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P, _P, C.POINTER(C.c_ubyte)]),
+    "fp_timer_accumulate": (_I, [_P, C.POINTER(_F), _I]),
     "fp_resize_normalize": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "fp_dets_to_crops": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I,
+                                _P, _P, _P, _P]),
     "fp_blaze_decode": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "fp_blaze_weighted_nms": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "fp_yolo_decode": (_I, [_P, _I, _I, _I, _I, _F, C.POINTER(_F), _P, _I64, _I64, _P]),

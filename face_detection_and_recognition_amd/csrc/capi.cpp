@@ -116,6 +116,19 @@ int fp_plan_validate(const fp_op* ops, int n_ops, size_t weight_floats, size_t a
   return FP_OK;
 }
 
+static int launch_op(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  switch (op.kind) {
+    case FP_OP_CONV: return fp_launch_conv(op, weights, arena, s);
+    case FP_OP_DWCONV: return fp_launch_dwconv(op, weights, arena, s);
+    case FP_OP_MAXPOOL: return fp_launch_maxpool(op, arena, s);
+    case FP_OP_UPSAMPLE2X: return fp_launch_upsample2x(op, arena, s);
+    case FP_OP_COPY: return fp_launch_copy(op, arena, s);
+    case FP_OP_L2NORM: return fp_launch_l2norm(op, arena, s);
+    case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
+    default: return FP_ERR_UNSUPPORTED;
+  }
+}
+
 int fp_plan_run(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
                 size_t arena_floats, void* stream) {
   if (!weights || !arena) return FP_ERR_INVALID_ARG;
@@ -123,18 +136,85 @@ int fp_plan_run(const fp_op* ops, int n_ops, const float* weights, size_t weight
   if (rc != FP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   for (int i = 0; i < n_ops; ++i) {
-    const fp_op& op = ops[i];
-    switch (op.kind) {
-      case FP_OP_CONV: rc = fp_launch_conv(op, weights, arena, s); break;
-      case FP_OP_DWCONV: rc = fp_launch_dwconv(op, weights, arena, s); break;
-      case FP_OP_MAXPOOL: rc = fp_launch_maxpool(op, arena, s); break;
-      case FP_OP_UPSAMPLE2X: rc = fp_launch_upsample2x(op, arena, s); break;
-      case FP_OP_COPY: rc = fp_launch_copy(op, arena, s); break;
-      case FP_OP_L2NORM: rc = fp_launch_l2norm(op, arena, s); break;
-      case FP_OP_BLAZEBLOCK: rc = fp_launch_blazeblock(op, weights, arena, s); break;
-      default: rc = FP_ERR_UNSUPPORTED;
-    }
+    rc = launch_op(ops[i], weights, arena, s);
     if (rc != FP_OK) return rc;
+  }
+  return FP_OK;
+}
+
+// ---- per-op timing with HIP events recorded on the launch stream (bench.py's live roofline figures) ----
+struct fp_timer {
+  int n;
+  hipEvent_t* start;
+  hipEvent_t* stop;
+  unsigned char* used;
+};
+
+int fp_timer_create(int n_ops, void** out) {
+  if (!out || n_ops <= 0) return FP_ERR_INVALID_ARG;
+  fp_timer* t = new fp_timer;
+  t->n = n_ops;
+  t->start = new hipEvent_t[n_ops];
+  t->stop = new hipEvent_t[n_ops];
+  t->used = new unsigned char[n_ops];
+  for (int i = 0; i < n_ops; ++i) {
+    t->used[i] = 0;
+    if (hipEventCreate(&t->start[i]) != hipSuccess || hipEventCreate(&t->stop[i]) != hipSuccess) {
+      fp_set_hip_error(hipGetLastError());
+      return FP_ERR_LAUNCH;
+    }
+  }
+  *out = t;
+  return FP_OK;
+}
+
+void fp_timer_destroy(void* timer) {
+  fp_timer* t = (fp_timer*)timer;
+  if (!t) return;
+  for (int i = 0; i < t->n; ++i) {
+    hipEventDestroy(t->start[i]);
+    hipEventDestroy(t->stop[i]);
+  }
+  delete[] t->start;
+  delete[] t->stop;
+  delete[] t->used;
+  delete t;
+}
+
+int fp_plan_run_timed(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
+                      size_t arena_floats, void* stream, void* timer, const unsigned char* op_mask) {
+  fp_timer* t = (fp_timer*)timer;
+  if (!weights || !arena || !t || !op_mask || t->n < n_ops) return FP_ERR_INVALID_ARG;
+  int rc = fp_plan_validate(ops, n_ops, weight_floats, arena_floats);
+  if (rc != FP_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_ops; ++i) {
+    t->used[i] = op_mask[i];
+    if (op_mask[i]) hipEventRecord(t->start[i], s);
+    rc = launch_op(ops[i], weights, arena, s);
+    if (rc != FP_OK) return rc;
+    if (op_mask[i]) hipEventRecord(t->stop[i], s);
+  }
+  return FP_OK;
+}
+
+// Adds the elapsed ms of every op timed by the LAST fp_plan_run_timed call into ms_accum[i]
+// (waits for those events; call it outside any latency-critical section).
+int fp_timer_accumulate(void* timer, float* ms_accum, int n_ops) {
+  fp_timer* t = (fp_timer*)timer;
+  if (!t || !ms_accum || n_ops > t->n) return FP_ERR_INVALID_ARG;
+  for (int i = 0; i < n_ops; ++i) {
+    if (!t->used[i]) continue;
+    if (hipEventSynchronize(t->stop[i]) != hipSuccess) {
+      fp_set_hip_error(hipGetLastError());
+      return FP_ERR_LAUNCH;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->start[i], t->stop[i]) != hipSuccess) {
+      fp_set_hip_error(hipGetLastError());
+      return FP_ERR_LAUNCH;
+    }
+    ms_accum[i] += ms;
   }
   return FP_OK;
 }

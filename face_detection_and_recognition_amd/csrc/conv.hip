@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int i = 0; i < 4; ++i) {
     long m = m0 + r0 + 32 * i;
     rv[i] = m < p.M;
-    long mm = rv[i] ? m : 0;
-    int img = (int)(mm / p.OHW);
-    int rem = (int)(mm - (long)img * p.OHW);
-    int oy = rem / p.OW, ox = rem - oy * p.OW;
+    const unsigned mm = rv[i] ? (unsigned)m : 0u;
+    const unsigned img = mm / (unsigned)p.OHW;
+    const unsigned rem = mm - img * (unsigned)p.OHW;
+    const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
     pixbase[i] = (long)img * p.in_ns;
     iy0[i] = oy * p.stride - p.pad_t;
     ix0[i] = ox * p.stride - p.pad_l;
@@ -169,30 +169,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 
   // Epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Per-column parameters are lane constants: fetch them once, before the store loop.
+  float sc[NB], bi[NB], sl[NB];
+  bool nv[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + nb * 32 + lr;
+    nv[nb] = n < p.Cout;
+    const int nn = nv[nb] ? n : 0;
+    sc[nb] = p.scale ? p.scale[nn] : 1.f;
+    bi[nb] = p.bias ? p.bias[nn] : 0.f;
+    sl[nb] = (p.act == FP_ACT_PRELU) ? p.slope[nn] : 0.f;
+  }
+  // (img, pix) of this wave's first row with one 32-bit division; the 16 rows follow by carry.
+  const unsigned mw = (unsigned)(m0 + wave * 32);
+  const unsigned uOHW = (unsigned)p.OHW;
+  const unsigned img_w = mw / uOHW;
+  const unsigned pix_w = mw - img_w * uOHW;
+  const int act = p.act, res_mode = p.res_mode;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
     const long m = m0 + wave * 32 + row;
     if (m >= p.M) continue;
-    const int img = (int)(m / p.OHW);
-    const int pix = (int)(m - (long)img * p.OHW);
+    unsigned img = img_w, pix = pix_w + (unsigned)row;
+    if (uOHW >= 32u) {
+      if (pix >= uOHW) { pix -= uOHW; ++img; }
+    } else {
+      const unsigned q = pix / uOHW;
+      img += q;
+      pix -= q * uOHW;
+    }
     float* orow = p.out + (long)img * p.out_ns + (long)pix * p.out_ld;
     const float* rrow = nullptr;
     const float* rrow2 = nullptr;
-    if (p.res_mode == FP_RES_ADD_BEFORE_ACT || p.res_mode == FP_RES_ADD_AFTER_ACT) {
+    if (res_mode == FP_RES_ADD_BEFORE_ACT || res_mode == FP_RES_ADD_AFTER_ACT) {
       rrow = p.res + (long)img * p.res_ns + (long)pix * p.res_ld;
-    } else if (p.res_mode == FP_RES_POOL2_BEFORE_ACT) {
-      const int oy = pix / p.OW, ox = pix - oy * p.OW;
+    } else if (res_mode == FP_RES_POOL2_BEFORE_ACT) {
+      const unsigned oy = pix / (unsigned)p.OW, ox = pix - oy * (unsigned)p.OW;
       rrow = p.res + (long)img * p.res_ns + ((long)(2 * oy) * p.res_W + 2 * ox) * p.res_ld;
       rrow2 = rrow + (long)p.res_W * p.res_ld;
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+      if (!nv[nb]) continue;
       const int n = n0 + nb * 32 + lr;
-      if (n >= p.Cout) continue;
-      float v = acc[nb][reg];
-      if (p.scale) v *= p.scale[n];
-      if (p.bias) v += p.bias[n];
+      float v = acc[nb][reg] * sc[nb] + bi[nb];
       float r = 0.f;
       if (rrow && n < p.res_C) {
         if (rrow2) {
@@ -203,11 +225,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
           r = rrow[n];
         }
       }
-      const float sl = (p.act == FP_ACT_PRELU) ? p.slope[n] : 0.f;
-      if (p.res_mode == FP_RES_ADD_AFTER_ACT)
-        v = apply_act(v, p.act, sl) + r;
+      if (res_mode == FP_RES_ADD_AFTER_ACT)
+        v = apply_act(v, act, sl[nb]) + r;
       else
-        v = apply_act(v + r, p.act, sl);
+        v = apply_act(v + r, act, sl[nb]);
       orow[(long)n * p.out_cmul] = v;
     }
   }
@@ -373,6 +394,7 @@ int fp_launch_conv(const fp_op& op, const float* weights, float* arena, hipStrea
   a.OHW = op.OH * op.OW;
   a.M = (long)op.N * a.OHW;
   if (a.act == FP_ACT_PRELU && !a.slope) return FP_ERR_INVALID_ARG;
+  if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;  // 32-bit row decode in the kernel
   const bool vec = (op.Cin % 4 == 0) && (op.in_ld % 4 == 0) && (op.in_off % 4 == 0) && (op.in_ns % 4 == 0);
   const int nblk32 = a.Npad / 32;
   int NB = 4;

@@ -382,6 +382,101 @@ __global__ __launch_bounds__(256) void yolo_nms_kernel(const float* __restrict__
   if (tid == 0) out_count[b] = nout;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Detections -> per-face crop rectangles, on device (keeps detect -> embed free of a host round trip).
+// fmt 0: BlazeFaceModel rows (ymin,xmin,ymax,xmax,...,score@16), normalised to the model input:
+//        column reorder (blazeface/model.py:70) + get_dets_bboxes_confs_lmarks_areas (utils/inference.py:11-58).
+// fmt 1: YOLOv5-face rows (x1,y1,x2,y2,conf@4,...) in model-input pixels: get_bboxes_confs_areas
+//        (yolov5_face/onnx/onnx_utils.py:313-340).
+// Both: conf > det_thres, 100*area/(iw*ih) > area_thres, scale_coords (utils/image.py:79-99: subtract pad,
+// divide by gain, clip to the frame), round half-to-even, then the crop of
+// face_extraction/extract_faces_from_dataset.py:289-303: int(), offsets (tx,ty,bx,by), clamp to the frame.
+// All fp32, in numpy's operation order for float32 inputs.  Faces are emitted in (frame, detection) order.
+struct CropArgs {
+  const float* dets;
+  const int* counts;
+  int B, max_dets, row, fmt, in_w, in_h, orig_w, orig_h;
+  float det_thres, area_thres, gain, pad_x, pad_y;
+  int tx, ty, bx, by, dst_w, dst_h, max_faces;
+  fp_resize_item* items;
+  float* info;
+  int* n_faces;
+};
+
+__device__ __forceinline__ bool crop_one(const CropArgs& p, const float* d, float& x1, float& y1, float& x2,
+                                         float& y2, float& conf) {
+  if (p.fmt == 0) {
+    conf = d[16];
+    if (!(conf > p.det_thres)) return false;
+    x1 = d[1] * (float)p.in_w; y1 = d[0] * (float)p.in_h; x2 = d[3] * (float)p.in_w; y2 = d[2] * (float)p.in_h;
+  } else {
+    conf = d[4];
+    if (!(conf > p.det_thres)) return false;
+    x1 = d[0]; y1 = d[1]; x2 = d[2]; y2 = d[3];
+  }
+  const float area = (x2 - x1) * (y2 - y1);
+  const float perc = area / (float)(p.in_w * p.in_h);
+  if (!(100.f * perc > p.area_thres)) return false;
+  x1 = (x1 - p.pad_x) / p.gain; x2 = (x2 - p.pad_x) / p.gain;
+  y1 = (y1 - p.pad_y) / p.gain; y2 = (y2 - p.pad_y) / p.gain;
+  x1 = fminf(fmaxf(x1, 0.f), (float)p.orig_w); x2 = fminf(fmaxf(x2, 0.f), (float)p.orig_w);
+  y1 = fminf(fmaxf(y1, 0.f), (float)p.orig_h); y2 = fminf(fmaxf(y2, 0.f), (float)p.orig_h);
+  x1 = rintf(x1); y1 = rintf(y1); x2 = rintf(x2); y2 = rintf(y2);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void dets_to_crops_kernel(CropArgs p) {
+  __shared__ int scan[256];
+  __shared__ int base_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int f0 = 0; f0 < p.B; f0 += 256) {
+    const int f = f0 + tid;
+    int n = 0, cnt = 0;
+    const float* D = nullptr;
+    if (f < p.B) {
+      n = min(max(p.counts[f], 0), p.max_dets);
+      D = p.dets + (long)f * p.max_dets * p.row;
+      for (int i = 0; i < n; ++i) {
+        float x1, y1, x2, y2, c;
+        if (crop_one(p, D + (long)i * p.row, x1, y1, x2, y2, c)) ++cnt;
+      }
+    }
+    scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan over the 256 frames of this chunk
+      int v = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    int slot = base_s + scan[tid] - cnt;
+    for (int i = 0; i < n; ++i) {
+      float x1, y1, x2, y2, c;
+      if (!crop_one(p, D + (long)i * p.row, x1, y1, x2, y2, c)) continue;
+      if (slot < p.max_faces) {
+        int x = (int)x1 + p.tx, y = (int)y1 + p.ty, xw = (int)x2 + p.bx, yh = (int)y2 + p.by;
+        x = max(x, 0); y = max(y, 0); xw = min(xw, p.orig_w); yh = min(yh, p.orig_h);
+        fp_resize_item it;
+        it.src_image = f;
+        it.sx = x; it.sy = y; it.sw = xw - x; it.sh = yh - y;
+        it.dx = 0; it.dy = 0; it.dw = p.dst_w; it.dh = p.dst_h;
+        if (it.sw <= 0 || it.sh <= 0) { it.dw = 0; it.dh = 0; }  // empty crop: canvas becomes pad colour
+        p.items[slot] = it;
+        float* o = p.info + (long)slot * 6;
+        o[0] = (float)f; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = c;
+      }
+      ++slot;
+    }
+    __syncthreads();
+    if (tid == 255) base_s += scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) p.n_faces[0] = base_s;  // may exceed max_faces: the host checks and raises
+}
+
 }  // namespace
 
 extern "C" {
@@ -455,6 +550,22 @@ int fp_yolo_w_nms(const float* pred, int B, int n_rows, float conf_thres, float 
                   size_t scratch_bytes, void* stream) {
   return yolo_nms_common(1, pred, B, n_rows, conf_thres, nms_thres, max_cand, max_out, out, out_count, keep_idx,
                          overflow, scratch, scratch_bytes, stream);
+}
+
+int fp_dets_to_crops(const float* dets, const int32_t* counts, int B, int max_dets, int row_floats, int fmt, int in_w,
+                     int in_h, int orig_w, int orig_h, float det_thres, float area_thres, float gain, float pad_x,
+                     float pad_y, int off_tx, int off_ty, int off_bx, int off_by, int dst_w, int dst_h, int max_faces,
+                     fp_resize_item* items, float* face_info, int32_t* n_faces, void* stream) {
+  if (!dets || !counts || !items || !face_info || !n_faces) return FP_ERR_INVALID_ARG;
+  if (B < 0 || max_dets <= 0 || max_faces <= 0 || in_w <= 0 || in_h <= 0 || orig_w <= 0 || orig_h <= 0 ||
+      dst_w <= 0 || dst_h <= 0 || !(gain > 0.f))
+    return FP_ERR_INVALID_ARG;
+  if ((fmt == 0 && row_floats < 17) || (fmt == 1 && row_floats < 5) || fmt < 0 || fmt > 1) return FP_ERR_INVALID_ARG;
+  CropArgs a{dets, counts, B, max_dets, row_floats, fmt, in_w, in_h, orig_w, orig_h, det_thres, area_thres, gain,
+             pad_x, pad_y, off_tx, off_ty, off_bx, off_by, dst_w, dst_h, max_faces, items, face_info, n_faces};
+  hipLaunchKernelGGL(dets_to_crops_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
 }
 
 }  // extern "C"

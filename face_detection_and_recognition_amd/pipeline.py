@@ -1,0 +1,100 @@
+"""Batched detect -> crop -> embed -> similarity-filter pipeline, resident on one GPU.
+
+This is the reference's own composition (face_extraction/extract_faces_from_dataset.py:270-307:
+``net.inf_func`` -> ``bbox_conf_area_func`` -> crop with offsets -> ``get_face_features``) followed by the
+similarity filter, run for a whole batch of frames at once: every stage is a HIP kernel launched on the
+caller's stream and the only host round trip is reading the number of faces found (it sizes the embedder batch).
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import similarity as S
+from .modules.mobile_facenet.utils import crops_to_input, mfn_lut
+from .modules.utils.image import letterbox_geometry
+
+FACE_OFFSETS = (-6, -1, 4, 5)   # tx, ty, bx, by  (extract_faces_from_dataset.py:285-287)
+
+
+def scale_coords_params(in_size, orig_size):
+    """gain / pad of scale_coords (modules/utils/image.py:83-87) as fp32 (numpy promotes python floats to the
+    float32 array dtype)."""
+    iw, ih = in_size
+    w, h = orig_size
+    gain = min(ih / h, iw / w)
+    pad_x, pad_y = (iw - w * gain) / 2, (ih - h * gain) / 2
+    return np.float32(gain), np.float32(pad_x), np.float32(pad_y)
+
+
+class FacePipeline:
+    """detector: a BlazeFaceModel or YOLOV5FaceModel (HIP); embedder: a HIP MobileFaceNet;
+    reference: (Nr, E) CUDA tensor of reference embeddings for the cosine filter (or None)."""
+
+    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=64):
+        self.det = detector
+        self.emb = embedder
+        self.tau = float(tau)
+        self.max_faces_per_frame = int(max_faces_per_frame)
+        self.bucket = int(bucket)
+        self.dev = embedder._device()
+        self.lut = mfn_lut(self.dev)
+        self.set_reference(reference)
+
+    def set_reference(self, reference):
+        self.reference = None if reference is None else reference.to(self.dev, torch.float32).contiguous()
+        self.rinv = None if reference is None else S.row_inv_norm(self.reference)
+
+    # -- stages ----------------------------------------------------------------------------------
+    def detect(self, frames):
+        """frames (B, H, W, 3) u8 BGR on device -> (dets, counts, fmt, row_floats)."""
+        return self.det.raw_batch(frames)
+
+    def crops(self, frames, dets, counts):
+        """Device-side B7 + crop arithmetic -> (items, info, n_faces tensor)."""
+        lib = L.load()
+        B, H, W, _ = frames.shape
+        cap = B * self.max_faces_per_frame
+        items = torch.empty((cap, 9), dtype=torch.int32, device=self.dev)
+        info = torch.empty((cap, 6), dtype=torch.float32, device=self.dev)
+        nf = torch.empty((1,), dtype=torch.int32, device=self.dev)
+        iw, ih = self.det.input_size
+        gain, px, py = scale_coords_params((iw, ih), (W, H))
+        fmt = getattr(self.det, "dets_fmt", 0)
+        row = dets.shape[-1]
+        tx, ty, bx, by = FACE_OFFSETS
+        L.check(lib.fp_dets_to_crops(L.ptr(dets), L.ptr(counts), B, dets.shape[1], row, fmt, iw, ih, W, H,
+                                     float(self.det.det_thres), float(self.det.bbox_area_thres), float(gain),
+                                     float(px), float(py), tx, ty, bx, by, 112, 112, cap, L.ptr(items), L.ptr(info),
+                                     L.ptr(nf), L.current_stream(self.dev)), "fp_dets_to_crops")
+        return items, info, nf
+
+    def embed(self, frames, items, n_faces):
+        """Crop + resize + normalise into the embedder's input, run Mobile-FaceNet.  -> (n_faces, E)."""
+        if n_faces == 0:
+            return torch.zeros((0, self.emb.embedding_size), device=self.dev)
+        n_pad = (n_faces + self.bucket - 1) // self.bucket * self.bucket
+        plan = self.emb.plan_for(n_pad)
+        crops_to_input(frames, items, n_faces, plan.input, self.lut)
+        plan.run()
+        return plan.out[:n_faces]
+
+    def filter(self, emb):
+        if self.reference is None or emb.shape[0] == 0:
+            return None
+        return S.cosine_filter(emb, self.reference, self.tau, rinv=self.rinv)
+
+    # -- whole step ------------------------------------------------------------------------------
+    def step(self, frames):
+        """One pass over a batch of frames.  Returns dict(n_faces, info, emb, best, arg, keep)."""
+        dets, counts = self.detect(frames)
+        items, info, nf = self.crops(frames, dets, counts)
+        n = int(nf.item())                      # the one host sync of the step
+        cap = items.shape[0]
+        if n > cap:
+            raise L.FacepathError(f"{n} faces in the batch exceed max_faces_per_frame*B = {cap}")
+        emb = self.embed(frames, items, n)
+        res = self.filter(emb)
+        out = dict(n_faces=n, info=info[:n], emb=emb)
+        if res is not None:
+            out.update(best=res[0], arg=res[1], keep=res[2])
+        return out

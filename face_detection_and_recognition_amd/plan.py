@@ -147,6 +147,7 @@ class PlanBuilder:
         self.w_floats = 0
         self.arena = Arena()
         self.peak = 0
+        self.alg_bytes = []   # op-granular algorithmic bytes per op, from LOGICAL channel counts
 
     # ---- memory ----
     def new_buf(self, H, W, C):
@@ -222,6 +223,7 @@ class PlanBuilder:
             op.res_C = min(res.C, out.C)
             op.res_H, op.res_W = res.H, res.W
         self.ops.append(op)
+        self.alg_bytes.append(4 * self.N * (x.H * x.W * cin + OH * OW * cout))
         return out
 
     def dwconv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
@@ -240,6 +242,7 @@ class PlanBuilder:
         if slope is not None:
             op.slope_off = self.add_weight(pad_vec(slope, x.C, 0.0))
         self.ops.append(op)
+        self.alg_bytes.append(4 * self.N * (x.H * x.W * c + out.H * out.W * c))
         return out
 
     def maxpool(self, x, out, k, stride, pad):
@@ -250,6 +253,7 @@ class PlanBuilder:
         op.stride = stride
         op.pad_t = op.pad_l = pad
         self.ops.append(op)
+        self.alg_bytes.append(0)
         return out
 
     def upsample2x(self, x, out):
@@ -257,6 +261,7 @@ class PlanBuilder:
         op = self._base(L.OP_UPSAMPLE2X, x, out, out.H, out.W)
         op.Cout = x.C
         self.ops.append(op)
+        self.alg_bytes.append(0)
         return out
 
     def copy(self, x, out):
@@ -264,12 +269,14 @@ class PlanBuilder:
         op = self._base(L.OP_COPY, x, out, out.H, out.W)
         op.Cout = x.C
         self.ops.append(op)
+        self.alg_bytes.append(0)
         return out
 
     def l2norm(self, x, out):
         op = self._base(L.OP_L2NORM, x, out, out.H, out.W)
         op.Cout = x.C
         self.ops.append(op)
+        self.alg_bytes.append(0)
         return out
 
     def finish(self):
@@ -284,6 +291,8 @@ class CompiledPlan:
         import torch
         ops, weights, arena_floats = builder.finish()
         self.n_ops = len(ops)
+        self.alg_bytes = list(builder.alg_bytes)
+        assert len(self.alg_bytes) == self.n_ops
         self.ops = (L.FpOp * max(self.n_ops, 1))(*ops)
         self.device = torch.device(device)
         self.weights = torch.from_numpy(weights).to(self.device)
@@ -302,10 +311,44 @@ class CompiledPlan:
                                   L.ptr(self.arena), self.arena_floats, L.current_stream(self.device))
         L.check(rc, "fp_plan_run")
 
+    # ---- measurement support (bench.py) ----
+    def new_timer(self):
+        t = C.c_void_p()
+        L.check(self.lib.fp_timer_create(max(self.n_ops, 1), C.byref(t)), "fp_timer_create")
+        return t
 
-def validate_on_host(builder):
-    """Host-only validation (no GPU): runs fp_plan_validate on the built ops."""
-    ops, weights, arena_floats = builder.finish()
-    arr = (L.FpOp * max(len(ops), 1))(*ops)
-    lib = L.load()
-    return lib.fp_plan_validate(arr, len(ops), int(weights.size), int(arena_floats))
+    def run_timed(self, timer, mask):
+        """Like run(), with HIP events recorded on the stream around the ops selected by mask (bytes, n_ops)."""
+        m = (C.c_ubyte * self.n_ops)(*mask)
+        rc = self.lib.fp_plan_run_timed(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
+                                        L.ptr(self.arena), self.arena_floats, L.current_stream(self.device), timer, m)
+        L.check(rc, "fp_plan_run_timed")
+
+    def accumulate(self, timer, ms):
+        """ms: ctypes float array of n_ops; adds the last timed run's per-op milliseconds."""
+        L.check(self.lib.fp_timer_accumulate(timer, ms, self.n_ops), "fp_timer_accumulate")
+
+    def destroy_timer(self, timer):
+        self.lib.fp_timer_destroy(timer)
+
+    def kernel_name(self, i):
+        """The HIP kernel family an op launches (matches the rocprofv3 kernel-trace names)."""
+        op = self.ops[i]
+        return op_kernel_name(op)
+
+    def algorithmic_bytes(self, i):
+        """Op-granular fp32 activation bytes of op i: a conv / linear reads its input once and
+        writes its output once (logical channel counts); epilogue-class ops (bias, BN, activation, residual,
+        pad, concat, pool, shuffle, upsample, l2norm) are free; a fused op counts the convs it contains."""
+        return self.alg_bytes[i]
+
+
+def op_kernel_name(op):
+    if op.kind == L.OP_CONV:
+        npad = round_up(op.Cout, 32) // 32
+        nb = 4 if npad % 4 == 0 else 3 if npad % 3 == 0 else 2 if npad % 2 == 0 else 1 if npad == 1 else 4
+        vec = op.Cin % 4 == 0 and op.in_ld % 4 == 0 and op.in_off % 4 == 0 and op.in_ns % 4 == 0
+        return f"conv_igemm_kernel<{nb}, {'true' if vec else 'false'}>"
+    return {L.OP_DWCONV: f"dwconv_kernel<{op.KH}>", L.OP_MAXPOOL: "maxpool_kernel",
+            L.OP_UPSAMPLE2X: "upsample2x_kernel", L.OP_COPY: "copy_kernel", L.OP_L2NORM: "l2norm_kernel",
+            L.OP_BLAZEBLOCK: "blazeblock_kernel"}.get(op.kind, "?")

@@ -1,0 +1,105 @@
+"""Synthetic benchmark workload (BASELINE.json configs[1]: BlazeFace back-camera, batch 256, 576x1024 frames).
+
+No weights and no datasets exist offline, so the workload is defined here, once, for
+bench.py, smoke() and the end-to-end tests:
+  * frames: uint8 (B, 576, 1024, 3) BGR, flat low-contrast background plus two high-contrast textured
+    patches per frame (the README's test video has two faces, /root/reference README.md:56);
+  * detector: BlazeFace-back with seeded synthetic weights (synth.py); the head is conditioned so that
+    random weights give well-formed boxes (w, h > 0) and scores that follow local contrast,
+    and the classifier bias is calibrated once, off the clock, so that ~`cand_per_frame` anchors pass the
+    score threshold per frame;
+  * embedder: Mobile-FaceNet(512) with seeded synthetic weights;
+  * reference set for the cosine filter: seeded unit-norm (n_ref, 512) embeddings.
+Nothing here is timed; it only builds inputs.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .modules.blazeface.blazeface import BlazeFace, generate_anchors
+from .modules.blazeface.model import BlazeFaceModel
+from .modules.mobile_facenet.mobile_facenet import MobileFaceNet
+from .synth import synth_state_dict
+
+FRAME_H, FRAME_W = 576, 1024
+
+
+def make_frames(B, device, seed=1234, h=FRAME_H, w=FRAME_W):
+    """Deterministic (seeded, generated on the host in small pieces) synthetic frames, returned on device."""
+    rng = np.random.default_rng(seed)
+    out = torch.empty((B, h, w, 3), dtype=torch.uint8, device=device)
+    # one shared low-contrast background tile + per-frame patches keeps host generation cheap
+    bg = (112 + rng.integers(-6, 7, size=(h, w, 3))).astype(np.uint8)
+    bg_t = torch.from_numpy(bg).to(device)
+    for i in range(B):
+        f = bg_t.clone()
+        for _ in range(2):
+            ph = int(rng.integers(h // 4, h // 2))
+            pw = ph
+            y0 = int(rng.integers(0, h - ph))
+            x0 = int(rng.integers(0, w - pw))
+            cells = rng.integers(0, 256, size=((ph + 7) // 8, (pw + 7) // 8, 3), dtype=np.uint8)
+            tex = np.repeat(np.repeat(cells, 8, axis=0), 8, axis=1)[:ph, :pw]
+            f[y0:y0 + ph, x0:x0 + pw] = torch.from_numpy(tex).to(device)
+        out[i] = f
+    return out
+
+
+def build_blazeface_back(device, seed=101, box_px=90.0):
+    net = BlazeFace(back_model=True)
+    sd = synth_state_dict(net.state_dict(), seed, residual_gain=0.5)
+    # well-formed boxes: small random offsets around the anchor, positive w/h of ~box_px (model-input pixels)
+    for name in ("regressor_8", "regressor_16"):
+        sd[name + ".weight"] = sd[name + ".weight"] * 0.05
+        b = sd[name + ".bias"].clone() * 0.0
+        b.view(-1, 16)[:, 2:4] = box_px
+        sd[name + ".bias"] = b
+    # scores follow feature magnitude (local contrast): non-negative classifier weights
+    for name in ("classifier_8", "classifier_16"):
+        sd[name + ".weight"] = sd[name + ".weight"].abs() * 0.5
+        sd[name + ".bias"] = sd[name + ".bias"] * 0.0
+    net.load_state_dict(sd)
+    net = net.to(device)
+    net.set_anchors(generate_anchors(True))
+    return net
+
+
+def calibrate_scores(model, frames, cand_per_frame=64):
+    """Shift the classifier biases so that ~cand_per_frame anchors per frame reach min_score_thresh."""
+    net = model.net
+    B = frames.shape[0]
+    plan = net.plan_for(B)
+    from .modules.utils.image import letterbox_batch
+    letterbox_batch(frames, model.input_size, net._preprocess_lut(), plan.input, pad_value=125, swap_rb=True)
+    plan.run()
+    c = plan.c.flatten().float()
+    q = 1.0 - cand_per_frame / 896.0
+    kth = torch.quantile(c[torch.randperm(c.numel(), device=c.device)[:min(c.numel(), 1_000_000)]], q)
+    t = net.min_score_thresh
+    delta = math.log(t / (1.0 - t)) - float(kth) + 1e-3
+    with torch.no_grad():
+        net.classifier_8.bias += delta
+        net.classifier_16.bias += delta
+    net._plans = {}
+    return delta
+
+
+def build_detector(device, calib_frames, cand_per_frame=64, det_thres=0.70, bbox_area_thres=0.12):
+    net = build_blazeface_back(device)
+    model = BlazeFaceModel("", det_thres, bbox_area_thres, "back", device=str(device), net=net)
+    calibrate_scores(model, calib_frames, cand_per_frame)
+    return model
+
+
+def build_embedder(device, seed=300):
+    net = MobileFaceNet(512)
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed))
+    return net.to(device)
+
+
+def make_reference(n_ref, device, seed=43, dim=512):
+    rng = np.random.default_rng(seed)
+    r = rng.normal(0, 1, (n_ref, dim)).astype(np.float32)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    return torch.from_numpy(r).to(device)

@@ -113,6 +113,20 @@ int fp_plan_run(const fp_op* ops /*host*/, int n_ops,
 /* Validation only (no GPU needed): same checks as fp_plan_run. */
 int fp_plan_validate(const fp_op* ops /*host*/, int n_ops, size_t weight_floats, size_t arena_floats);
 
+/*
+ * Per-op timing for measurement (bench.py): fp_plan_run with a hipEvent pair recorded ON `stream`
+ * around every op whose op_mask[i] != 0.  A timer owns n_ops event pairs (host objects, no device
+ * memory); fp_timer_accumulate waits for the events of the last timed run of that timer and adds
+ * each op's elapsed milliseconds into ms_accum[i] (host array).  Use one timer per in-flight run.
+ */
+int fp_timer_create(int n_ops, void** out_timer);
+void fp_timer_destroy(void* timer);
+int fp_plan_run_timed(const fp_op* ops /*host*/, int n_ops,
+                      const float* weights, size_t weight_floats,
+                      float* arena, size_t arena_floats,
+                      void* stream, void* timer, const unsigned char* op_mask /*host, n_ops*/);
+int fp_timer_accumulate(void* timer, float* ms_accum /*host, n_ops*/, int n_ops);
+
 /* ------------------------------------------------------------------------- */
 /* 2. Image front end                                                          */
 /* ------------------------------------------------------------------------- */
@@ -129,8 +143,10 @@ int fp_plan_validate(const fp_op* ops /*host*/, int n_ops, size_t weight_floats,
  * INTER_LINEAR u8 fixed-point scheme (11-bit coefficients); cv2 is absent in
  * the build container so this boundary is "parity unpinned" (DESIGN.md).
  *
- * rects: int32 [n_items][8] = {src_image, sx0, sy0, sw, sh, dx0, dy0, (unused)} followed by
- * dst size dw, dh given by dst_w/dst_h of the resized region per item in rects[.][7]... see below.
+ * One item = one canvas: item i resizes its source rectangle of frame src_image into the
+ * destination rectangle (dx,dy,dw,dh) of canvas i (letterbox: the padded sub-rectangle; face crop:
+ * the whole 112x112 canvas).  Items live in DEVICE memory (they may be produced by
+ * fp_dets_to_crops); source rectangles are clamped to the frame inside the kernel.
  */
 typedef struct fp_resize_item {
   int32_t src_image;   /* index into frames */
@@ -143,6 +159,23 @@ int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int fr
                         float* canvas, int canvas_h, int canvas_w, int canvas_c /* >=3, extra channels zeroed */,
                         const float* lut256 /*device, 256 floats*/, int pad_value, int swap_rb,
                         void* stream);
+
+/*
+ * Detections -> face crop rectangles on device.  fmt 0: BlazeFace rows (ymin,xmin,ymax,xmax,...,score@16)
+ * normalised to the model input — column reorder (fde/modules/blazeface/model.py:70) +
+ * get_dets_bboxes_confs_lmarks_areas (fde/modules/utils/inference.py:11-58).  fmt 1: YOLOv5-face rows
+ * (x1,y1,x2,y2,conf@4) in input pixels — get_bboxes_confs_areas (fde/modules/yolov5_face/onnx/onnx_utils.py:313-340).
+ * Then scale_coords/clip/round (fde/modules/utils/image.py:62-99) and the crop arithmetic of
+ * fde/face_extraction/extract_faces_from_dataset.py:289-303 (int(), offsets, clamp).  gain/pad are
+ * scale_coords' values computed by the caller.  items[max_faces], face_info[max_faces][6] =
+ * (frame, x1, y1, x2, y2, conf) in original-frame pixels (rounded), n_faces[1] = total found (the caller
+ * must check n_faces <= max_faces).  Faces are ordered by (frame, detection).
+ */
+int fp_dets_to_crops(const float* dets, const int32_t* counts, int B, int max_dets, int row_floats, int fmt,
+                     int in_w, int in_h, int orig_w, int orig_h, float det_thres, float area_thres,
+                     float gain, float pad_x, float pad_y, int off_tx, int off_ty, int off_bx, int off_by,
+                     int dst_w, int dst_h, int max_faces,
+                     fp_resize_item* items, float* face_info, int32_t* n_faces, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* 3. BlazeFace post-processing                                                */
