@@ -92,6 +92,9 @@ def load():
         raise FacepathError(
             f"{LIB_PATH} not found: the HIP extension is not built and there is no CPU fallback. "
             "Run `make -C face_detection_and_recognition_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch first so that this
+    # library binds to the HIP runtime torch already loaded: one runtime per process, shared streams/memory.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

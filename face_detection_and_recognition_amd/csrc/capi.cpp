@@ -172,8 +172,8 @@ void fp_timer_destroy(void* timer) {
   fp_timer* t = (fp_timer*)timer;
   if (!t) return;
   for (int i = 0; i < t->n; ++i) {
-    hipEventDestroy(t->start[i]);
-    hipEventDestroy(t->stop[i]);
+    (void)hipEventDestroy(t->start[i]);
+    (void)hipEventDestroy(t->stop[i]);
   }
   delete[] t->start;
   delete[] t->stop;
@@ -190,10 +190,10 @@ int fp_plan_run_timed(const fp_op* ops, int n_ops, const float* weights, size_t 
   hipStream_t s = (hipStream_t)stream;
   for (int i = 0; i < n_ops; ++i) {
     t->used[i] = op_mask[i];
-    if (op_mask[i]) hipEventRecord(t->start[i], s);
+    if (op_mask[i]) (void)hipEventRecord(t->start[i], s);
     rc = launch_op(ops[i], weights, arena, s);
     if (rc != FP_OK) return rc;
-    if (op_mask[i]) hipEventRecord(t->stop[i], s);
+    if (op_mask[i]) (void)hipEventRecord(t->stop[i], s);
   }
   return FP_OK;
 }

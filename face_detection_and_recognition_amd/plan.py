@@ -306,7 +306,11 @@ class CompiledPlan:
         """A torch view [N, H, W, C] of an arena buffer (no copy)."""
         return self.arena[buf.off: buf.off + N * buf.ns].view(N, buf.H, buf.W, buf.C)
 
+    _timing = None   # (timer, mask) set by bench.py around a timed step; None = plain fp_plan_run
+
     def run(self):
+        if self._timing is not None:
+            return self.run_timed(*self._timing)
         rc = self.lib.fp_plan_run(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
                                   L.ptr(self.arena), self.arena_floats, L.current_stream(self.device))
         L.check(rc, "fp_plan_run")
@@ -352,3 +356,11 @@ def op_kernel_name(op):
     return {L.OP_DWCONV: f"dwconv_kernel<{op.KH}>", L.OP_MAXPOOL: "maxpool_kernel",
             L.OP_UPSAMPLE2X: "upsample2x_kernel", L.OP_COPY: "copy_kernel", L.OP_L2NORM: "l2norm_kernel",
             L.OP_BLAZEBLOCK: "blazeblock_kernel"}.get(op.kind, "?")
+
+
+def validate_on_host(builder):
+    """Host-only validation (no GPU): runs fp_plan_validate on the built ops."""
+    ops, weights, arena_floats = builder.finish()
+    arr = (L.FpOp * max(len(ops), 1))(*ops)
+    lib = L.load()
+    return lib.fp_plan_validate(arr, len(ops), int(weights.size), int(arena_floats))
