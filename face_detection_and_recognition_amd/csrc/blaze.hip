@@ -1,5 +1,220 @@
-// blaze.hip — fused BlazeBlock kernel (placeholder until the fused kernel lands; the planner emits
-// DWCONV + CONV for BlazeBlocks unless asked for the fused op).
+// blaze.hip — fused BlazeBlock (fde/modules/blazeface/blazeface.py:12-47) for gfx950.
+//
+//   y = ReLU( pw1x1( dw3x3_stride_s(h) ) + shortcut ),   h = x (s=1, pad 1) | pad(x,(0,2,0,2)) (s=2, pad 0)
+//   shortcut = x (s=1) | maxpool2x2(x) (s=2), zero-padded on channels when Cout > Cin.
+//
+// The unfused pair (DWCONV + CONV) writes the depthwise result to HBM and reads it back, and reads x a second
+// time for the shortcut: 4 tensor passes.  Here one workgroup owns 128 consecutive output pixels (NHWC, so its
+// output is ONE contiguous byte range) and keeps everything in between on chip:
+//   phase 1  all 256 lanes: depthwise 3x3 for (pixel, 4-channel group) items straight from global memory with
+//            16-B loads (the 9 taps of neighbouring pixels hit L1/L2; the block->tile map below keeps vertically
+//            adjacent tiles on one XCD so the halo rows are L2 hits, not HBM re-reads).  The result goes to an LDS
+//            tile A[128][K+4]; the shortcut value is a by-product (s=1: the centre tap; s=2: max of taps
+//            (0..1,0..1), which ARE the 2x2 pool window) and goes to a second LDS tile.
+//   phase 2  4 waves x 32 rows: v_mfma_f32_32x32x2_f32 over K = Cin against the packed 1x1 weights in LDS
+//            (same fragment scheme as conv.hip: one ds_read_b128 per 4 k-steps, row stride K+4 floats -> an odd
+//            number of 16-B slots -> conflict free).
+//   phase 3  epilogue in registers (bias + shortcut from LDS + ReLU), transposed through LDS so the tile leaves
+//            the CU as fully coalesced 16-B stores.
+// HBM traffic per block-layer: x once + y once (op-granular model counts 4 passes).
 #include "common.h"
 
-int fp_launch_blazeblock(const fp_op&, const float*, float*, hipStream_t) { return FP_ERR_UNSUPPORTED; }
+namespace {
+
+struct BlazeArgs {
+  const float* in;
+  float* out;
+  const float* wd;   // [9][Cin]
+  const float* bd;   // [Cin]
+  const float* wp;   // packed [Kpad/4][Npad][4]
+  const float* bp;   // [Cout]
+  int N, H, W, OH, OW, Cin, Cout, stride;
+  int in_ld, out_ld;
+  long in_ns, out_ns;
+  int Kpad, Npad, OHW, C4, res_C;
+  long M;
+  int ntiles;
+};
+
+constexpr int TM = 128;
+
+template <int NB>
+__global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LDT = p.Kpad + 4;          // A tile row stride
+  const int LDS_ = p.Cin + 4;          // shortcut tile row stride
+  float* At = smem;                                  // [TM][LDT]   (later reused as the output tile [TM][Cout])
+  const int a_floats = TM * (LDT > p.Cout ? LDT : p.Cout);
+  float* St = At + a_floats;                         // [TM][LDS_]
+  float* Bs = St + TM * LDS_;                        // [Kpad/4][Npad][4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+
+  // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous range of tiles: vertically adjacent rows (the 3x3 halo) then meet in the same L2.  Bijective
+  // for any ntiles (cdna_hip_programming.md T1).
+  int tile;
+  {
+    const int b = blockIdx.x, q = p.ntiles / 8, r = p.ntiles % 8, xcd = b & 7, k = b >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const long m0 = (long)tile * TM;
+
+  // stage the pointwise weights
+  const int nB4 = (p.Kpad >> 2) * p.Npad;
+  for (int i = tid; i < nB4; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.wp + (long)i * 4);
+
+  // phase 1: depthwise + shortcut
+  const int items = TM * p.C4;
+  const int KC4 = p.Kpad >> 2;  // A columns (in float4) incl. zero padding
+  for (int it = tid; it < TM * KC4; it += 256) {
+    const int r = it / KC4, c4 = it - r * KC4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+    const long m = m0 + r;
+    if (c4 < p.C4 && m < p.M) {
+      const unsigned mm = (unsigned)m;
+      const unsigned img = mm / (unsigned)p.OHW;
+      const unsigned rem = mm - img * (unsigned)p.OHW;
+      const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
+      const int c = c4 * 4;
+      const float* ib = p.in + (long)img * p.in_ns + c;
+      if (p.stride == 1) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = oy - 1 + ky;
+          if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox - 1 + kx;
+            if (ix < 0 || ix >= p.W) continue;
+            const f32x4 x = *(const f32x4*)(ib + ((long)iy * p.W + ix) * p.in_ld);
+            const f32x4 wv = *(const f32x4*)(p.wd + (ky * 3 + kx) * p.Cin + c);
+            acc += x * wv;
+            if (ky == 1 && kx == 1) sc = x;
+          }
+        }
+      } else {
+        const float ninf = -__builtin_huge_valf();
+        sc = (f32x4){ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = 2 * oy + ky;
+          if (iy >= p.H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx;
+            if (ix >= p.W) continue;
+            const f32x4 x = *(const f32x4*)(ib + ((long)iy * p.W + ix) * p.in_ld);
+            const f32x4 wv = *(const f32x4*)(p.wd + (ky * 3 + kx) * p.Cin + c);
+            acc += x * wv;
+            if (ky < 2 && kx < 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sc[e] = fmaxf(sc[e], x[e]);
+            }
+          }
+        }
+      }
+      acc += *(const f32x4*)(p.bd + c);
+    }
+    *(f32x4*)&At[r * LDT + c4 * 4] = acc;
+    if (c4 < p.C4) *(f32x4*)&St[r * LDS_ + c4 * 4] = sc;
+  }
+  (void)items;
+  __syncthreads();
+
+  // phase 2: 1x1 conv on the MFMA pipe
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+  const float* arow = &At[(wave * 32 + lr) * LDT + 4 * h];
+  const int ngroups = p.Kpad >> 3;
+  for (int kq = 0; kq < ngroups; ++kq) {
+    const f32x4 a = *(const f32x4*)(arow + kq * 8);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const f32x4 b = *(const f32x4*)&Bs[((kq * 2 + h) * p.Npad + nb * 32 + lr) * 4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[nb], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done reading At before it becomes the output tile
+
+  // phase 3: epilogue -> LDS output tile [TM][Cout] -> coalesced 16-B stores
+  float* Ot = At;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = nb * 32 + lr;
+    if (n < p.Cout) {
+      const float bias = p.bp[n];
+      const bool has_sc = n < p.res_C;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        float v = acc[nb][reg] + bias;
+        if (has_sc) v += St[row * LDS_ + n];
+        Ot[row * p.Cout + n] = v > 0.f ? v : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // rows m0 .. m0+TM-1 are consecutive pixels of a dense NHWC tensor (out_ld == Cout, out_ns == OHW*Cout)
+    const long rows_left = p.M - m0;
+    const int nrows = rows_left < TM ? (int)rows_left : TM;
+    const int n4 = nrows * p.Cout / 4;
+    float* obase = p.out + m0 * p.Cout;
+    for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+  }
+}
+
+}  // namespace
+
+size_t fp_blazeblock_lds_bytes(int Cin, int Cout) {
+  const int Kpad = (int)fp_round_up(Cin, 8), Npad = (int)fp_round_up(Cout, 32);
+  const int LDT = Kpad + 4;
+  const size_t a = (size_t)TM * (LDT > Cout ? LDT : Cout);
+  return 4 * (a + (size_t)TM * (Cin + 4) + (size_t)Kpad * Npad);
+}
+
+int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  // op fields: w_off = depthwise weights [9][Cin], scale_off = depthwise bias, slope_off = packed pointwise
+  // weights, bias_off = pointwise bias; res_C = channels of the shortcut (= logical Cin).
+  if (op.KH != 3 || op.KW != 3 || (op.stride != 1 && op.stride != 2)) return FP_ERR_UNSUPPORTED;
+  if (op.Cin % 4 || op.Cout % 4 || op.in_ld % 4 || op.in_off % 4 || op.in_ns % 4 || op.out_off % 4) return FP_ERR_ALIGNMENT;
+  if (op.out_cmul != 1 || op.out_ld != op.Cout || op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return FP_ERR_UNSUPPORTED;
+  if (op.stride == 1 && (op.OH != op.H || op.OW != op.W)) return FP_ERR_INVALID_ARG;
+  if (op.stride == 2 && (op.H % 2 || op.W % 2 || op.OH != op.H / 2 || op.OW != op.W / 2)) return FP_ERR_INVALID_ARG;
+  if (op.Cout > 128 || op.res_C > op.Cin) return FP_ERR_UNSUPPORTED;
+  const size_t lds = fp_blazeblock_lds_bytes(op.Cin, op.Cout);
+  if (lds > 64 * 1024) return FP_ERR_UNSUPPORTED;  // the planner emits the unfused pair for wider blocks
+  BlazeArgs a;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.wd = weights + op.w_off;
+  a.bd = weights + op.scale_off;
+  a.wp = weights + op.slope_off;
+  a.bp = weights + op.bias_off;
+  a.N = op.N; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.Cin = op.Cin; a.Cout = op.Cout;
+  a.stride = op.stride; a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  a.Kpad = (int)fp_round_up(op.Cin, 8);
+  a.Npad = (int)fp_round_up(op.Cout, 32);
+  a.OHW = op.OH * op.OW;
+  a.C4 = op.Cin / 4;
+  a.res_C = op.res_C;
+  a.M = (long)op.N * a.OHW;
+  if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;
+  a.ntiles = fp_ceil_div(a.M, TM);
+  dim3 grid((unsigned)a.ntiles), block(256);
+  switch (a.Npad / 32) {
+    case 1: hipLaunchKernelGGL((blazeblock_kernel<1>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((blazeblock_kernel<2>), grid, block, lds, s, a); break;
+    case 3: hipLaunchKernelGGL((blazeblock_kernel<3>), grid, block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((blazeblock_kernel<4>), grid, block, lds, s, a); break;
+    default: return FP_ERR_UNSUPPORTED;
+  }
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}

@@ -29,6 +29,8 @@ class BlazeBlock(_NoCompute):
             ConvParams(in_channels, in_channels, kernel_size, stride, padding, groups=in_channels, bias=True),
             ConvParams(in_channels, out_channels, 1, 1, 0, bias=True))
 
+    FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
+
     def emit(self, pb, x):
         dw, pw = self.convs[0], self.convs[1]
         if self.stride == 2:
@@ -38,6 +40,11 @@ class BlazeBlock(_NoCompute):
         else:
             OH, OW, pad = x.H, x.W, (1, 1)
             res_mode = L.RES_ADD_BEFORE_ACT
+        if (BlazeBlock.FUSE and self.kernel_size == 3 and x.coff == 0 and
+                pb.blazeblock_lds_bytes(x.C, cpad(self.out_channels)) <= 64 * 1024):
+            y = pb.new_buf(OH, OW, self.out_channels)
+            pb.blazeblock(x, npy(dw.weight), npy(dw.bias), npy(pw.weight), npy(pw.bias), y.view(), self.stride)
+            return y
         t = pb.new_buf(OH, OW, self.in_channels)
         pb.dwconv(x, npy(dw.weight), t.view(), stride=self.stride, pad=pad, bias=npy(dw.bias))
         y = pb.new_buf(OH, OW, self.out_channels)

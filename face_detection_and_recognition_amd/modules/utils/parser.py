@@ -1,21 +1,25 @@
-"""CLI surface of the reference (face_detection_and_extraction/modules/utils/parser.py:10-62), with the
+"""CLI surface of the reference (face_detection_and_extraction/modules/utils/parser.py:5-62), with the
 device choices extended by the HIP spellings."""
 import argparse
 
 
 class ArgumentParserMod(argparse.ArgumentParser):
-    """parser.py:10-34: an ArgumentParser whose arguments can be removed again by the entry points."""
+    """parser.py:5-34: an ArgumentParser whose arguments can be removed again by the entry points.
+    Unlike the reference (which leaves the option strings registered), removal here is complete, so a
+    removed flag is rejected and can be re-added without conflict_handler='resolve'."""
 
-    def remove_argument(self, arg: str):
-        for action in list(self._actions):
-            if (vars(action)['option_strings'] and vars(action)['option_strings'][0] == arg) or vars(action)['dest'] == arg:
-                self._remove_action(action)
-        for action in list(self._action_groups):
-            for ga in list(action._group_actions):
-                if (vars(ga)['option_strings'] and vars(ga)['option_strings'][0] == arg) or vars(ga)['dest'] == arg:
-                    action._group_actions.remove(ga)
-        for opt in [arg]:
-            self._option_string_actions.pop(opt, None)
+    def remove_argument(self, arg):
+        names = arg if isinstance(arg, (list, tuple)) else [arg]
+        for name in names:
+            for action in list(self._actions):
+                opts = vars(action)['option_strings']
+                if (opts and opts[0] == name) or vars(action)['dest'] == name:
+                    self._remove_action(action)
+                    for o in opts:
+                        self._option_string_actions.pop(o, None)
+                    for group in self._action_groups:
+                        if action in group._group_actions:
+                            group._group_actions.remove(action)
 
     def remove_arguments(self, arg_list):
         for a in arg_list:

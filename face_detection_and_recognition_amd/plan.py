@@ -245,6 +245,33 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * c + out.H * out.W * c))
         return out
 
+    @staticmethod
+    def blazeblock_lds_bytes(cin_phys, cout_phys):
+        """Mirror of fp_blazeblock_lds_bytes (csrc/blaze.hip): the fused kernel needs <= 64 KiB of LDS."""
+        kpad, npad = round_up(cin_phys, 8), round_up(cout_phys, 32)
+        a = 128 * max(kpad + 4, cout_phys)
+        return 4 * (a + 128 * (cin_phys + 4) + kpad * npad)
+
+    def blazeblock(self, x, wd, bd, wp, bp, out, stride):
+        """Fused BlazeBlock (blazeface.py:12-47): dw3x3(stride) -> 1x1 -> + shortcut -> ReLU in one kernel."""
+        cin = wd.shape[0]
+        cout = wp.shape[0]
+        assert out.cmul == 1 and out.coff == 0 and out.buf.ld == out.C
+        op = self._base(L.OP_BLAZEBLOCK, x, out, out.H, out.W)
+        op.Cout = out.C
+        op.KH = op.KW = 3
+        op.stride = stride
+        op.pad_t = op.pad_l = 1 if stride == 1 else 0
+        op.res_C = min(cin, x.C)
+        op.w_off = self.add_weight(pack_dw_weight(wd, x.C))
+        op.scale_off = self.add_weight(pad_vec(bd, x.C, 0.0))
+        op.slope_off = self.add_weight(pack_conv_weight(wp, x.C, out.C))
+        op.bias_off = self.add_weight(pad_vec(bp, out.C, 0.0))
+        self.ops.append(op)
+        opix = out.H * out.W
+        self.alg_bytes.append(4 * self.N * (x.H * x.W * cin + opix * cin + opix * cin + opix * cout))
+        return out
+
     def maxpool(self, x, out, k, stride, pad):
         assert out.C == x.C
         op = self._base(L.OP_MAXPOOL, x, out, out.H, out.W)

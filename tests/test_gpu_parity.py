@@ -67,6 +67,47 @@ def test_blazeface_forward_vs_reference_golden(dev, back):
     assert rel_err(r2.cpu().numpy(), g["r"]) < 1e-4
 
 
+@pytest.mark.parametrize("back", [True, False])
+def test_blazeface_fused_and_unfused_plans_agree(dev, back):
+    """FP_OP_BLAZEBLOCK (csrc/blaze.hip) against the DWCONV + CONV pair and the reference golden."""
+    tag = "back" if back else "front"
+    g = golden(f"blazeface_{tag}_forward")
+    x = torch.from_numpy(g["x_u8"]).to(dev)
+    outs = {}
+    for fuse in (True, False):
+        BlazeBlock.FUSE = fuse
+        try:
+            net = BlazeFace(back)
+            net.load_state_dict(synth_state_dict(net.state_dict(), int(g["seed"]), residual_gain=0.5))
+            net = net.to(dev)
+            plan = net.plan_for(2)
+            kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
+            assert (L.OP_BLAZEBLOCK in kinds) == fuse
+            r, c = net.raw_from_u8_nhwc(x)
+            torch.cuda.synchronize()
+            outs[fuse] = (r.cpu().numpy().copy(), c.cpu().numpy().copy())
+        finally:
+            BlazeBlock.FUSE = True
+    for fuse in (True, False):
+        assert rel_err(outs[fuse][0], g["r"]) < 1e-4 and rel_err(outs[fuse][1], g["c"]) < 1e-4
+    assert rel_err(outs[True][0], outs[False][0]) < 1e-5
+
+
+def test_blazeblock_fused_ragged_tail(dev):
+    """M = N*OH*OW not a multiple of the 128-row tile, odd batch: the tail tile must not write out of range."""
+    rng = np.random.default_rng(12)
+    for stride, cin, cout, hw in ((1, 24, 24, 10), (2, 24, 48, 10), (1, 48, 48, 6), (1, 28, 32, 6)):
+        blk = BlazeBlock(cin, cout, stride=stride)
+        sd = synth_state_dict(blk.state_dict(), 900 + cin + stride)
+        blk.load_state_dict(sd)
+        x = rng.normal(0, 1, (3, cin, hw, hw)).astype(np.float32)
+        y = run_block(blk, x, dev, None, cout)
+        xt = torch.from_numpy(x)
+        ref = blazeface_ref._blaze_block({k: v for k, v in sd.items()}, "", xt, stride).numpy()
+        assert y.shape == ref.shape
+        assert rel_err(y, ref) < 1e-5
+
+
 def test_blazeface_decode_vs_reference_golden(dev, lib):
     g = golden("blazeface_decode")
     B, A = g["raw_box"].shape[:2]

@@ -1,0 +1,109 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/facepath.h declares,
+plans validate, state_dict keys match the reference's names, helpers behave.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+from face_detection_and_recognition_amd import _lib as L
+from face_detection_and_recognition_amd.modules.blazeface.blazeface import BlazeFace, generate_anchors
+from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import MobileFaceNet
+from face_detection_and_recognition_amd.modules.utils import image as uimage
+from face_detection_and_recognition_amd.modules.utils.inference import get_dets_bboxes_confs_lmarks_areas
+from face_detection_and_recognition_amd.modules.utils.parser import get_argparse
+from face_detection_and_recognition_amd.plan import PlanBuilder, pack_conv_weight, validate_on_host
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "facepath.h")).read()
+    declared = set(re.findall(r"\b(fp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fp_status"}
+    assert declared, "no declarations parsed"
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"declared in facepath.h but not exported: {missing}"
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    assert lib.fp_abi_version() == 1
+    assert lib.fp_strerror(-2).decode().startswith("op touches")
+
+
+def test_struct_layout_matches_header():
+    # 22 int32 + 10 int64 = 168 bytes; fp_resize_item = 9 int32
+    assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8
+    assert ctypes.sizeof(L.FpResizeItem) == 36
+
+
+def test_plans_validate_and_reject_bad_offsets(lib):
+    for net in (BlazeFace(True), BlazeFace(False), MobileFaceNet(512)):
+        pb = net._emit(3)[0]
+        assert validate_on_host(pb) == 0
+        ops, weights, arena = pb.finish()
+        arr = (L.FpOp * len(ops))(*ops)
+        assert lib.fp_plan_validate(arr, len(ops), weights.size, arena - 1) == -2          # arena too small
+        assert lib.fp_plan_validate(arr, len(ops), weights.size - 1, arena) == -2          # weight blob too small
+        bad = (L.FpOp * len(ops))(*ops)
+        bad[0].N = 0
+        assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
+    assert lib.fp_plan_validate(None, 0, 0, 0) == -1
+
+
+def test_null_and_size_argument_checks(lib):
+    assert lib.fp_blaze_decode(None, None, None, 1, 896, 1., 1., 1., 1., 100., .5, None, None, None) == -1
+    assert lib.fp_cosine_filter(None, None, 1, None, None, 1, 512, 0., None, None, None, None, None) == -1
+    assert lib.fp_yolo_nms_scratch_bytes(2, 1024) == 2 * 1024 * 32
+    assert lib.fp_yolo_nms_scratch_bytes(0, 1024) == 0
+
+
+def test_weight_packing_layout():
+    w = np.arange(2 * 3 * 1 * 1, dtype=np.float32).reshape(2, 3, 1, 1)     # Cout=2, Cin=3
+    p = pack_conv_weight(w, 4, 2).reshape(2, 32, 4)                        # Kpad=8 -> 2 quads, Npad=32
+    for k in range(3):
+        for n in range(2):
+            assert p[k // 4, n, k % 4] == w[n, k, 0, 0]
+    assert p[:, 2:, :].sum() == 0 and p[0, :, 3].sum() == 0
+
+
+def test_anchor_generator_and_state_dict_keys():
+    a = generate_anchors(True)
+    assert a.shape == (896, 4) and np.all(a[:, 2:] == 1)
+    np.testing.assert_allclose(a[0, :2], [1 / 32, 1 / 32])
+    np.testing.assert_allclose(a[512, :2], [1 / 16, 1 / 16])
+    keys = list(BlazeFace(True).state_dict())
+    assert keys[:4] == ["backbone.0.weight", "backbone.0.bias", "backbone.2.convs.0.weight", "backbone.2.convs.0.bias"]
+    assert "final.convs.1.bias" in keys and "regressor_16.weight" in keys
+    mk = list(MobileFaceNet(512).state_dict())
+    for k in ("conv1.conv.weight", "conv1.bn.running_var", "conv1.prelu.weight", "conv_23.conv.conv.weight",
+              "conv_3.model.0.conv_dw.bn.weight", "linear.weight", "bn.num_batches_tracked"):
+        assert k in mk
+
+
+def test_no_cpu_fallback():
+    net = BlazeFace(True)
+    with pytest.raises(L.FacepathError):
+        net.plan_for(1)                      # parameters on CPU: refuses instead of falling back
+    with pytest.raises(RuntimeError):
+        net.backbone[2](torch.zeros(1, 24, 8, 8))   # containers never compute
+
+
+def test_post_processing_helpers_match_reference_golden():
+    g = golden("utils_postprocess")
+    post = get_dets_bboxes_confs_lmarks_areas(g["blaze_dets"].copy(), (1024, 576), (256, 256), 0.7, 0.12)
+    np.testing.assert_array_equal(post.boxes, g["blaze_boxes"])
+    np.testing.assert_array_equal(post.bbox_lmarks, g["blaze_lmarks"])
+    np.testing.assert_array_equal(post.bbox_confs, g["blaze_confs"])
+    np.testing.assert_allclose(uimage.standardize_image(g["std_in"].astype(np.float64)), g["std_out"], atol=1e-6)
+    assert uimage.check_img_size(630) == 640 and uimage.make_divisible(33, 32) == 64
+    assert uimage.letterbox_geometry(1024, 576, 256, 256) == (256, 144, 0, 56)
+    assert abs(uimage.calculate_bbox_iou((0, 0, 2, 2), (1, 1, 3, 3)) - 1 / 7) < 1e-12
+
+
+def test_cli_flags():
+    p = get_argparse()
+    a = p.parse_args(["-i", "x.jpg", "--md", "w.pth", "--dt", "0.5", "--at", "0.2", "-d", "hip:1"])
+    assert (a.input_src, a.model, a.det_thres, a.bbox_area_thres, a.device) == ("x.jpg", "w.pth", 0.5, 0.2, "hip:1")
+    p.remove_argument("model")
+    with pytest.raises(SystemExit):
+        p.parse_args(["--md", "w"])
