@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
   const int a_floats = TM * (LDT > p.Cout ? LDT : p.Cout);
   float* St = At + a_floats;                         // [TM][LDS_]
   float* Bs = St + TM * LDS_;                        // [Kpad/4][Npad][4]
+  float* Ws = Bs + p.Kpad * p.Npad;                  // depthwise weights [9][Cin] + bias [Cin]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
@@ -65,62 +66,58 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
   const int nB4 = (p.Kpad >> 2) * p.Npad;
   for (int i = tid; i < nB4; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.wp + (long)i * 4);
 
-  // phase 1: depthwise + shortcut
-  const int items = TM * p.C4;
+  // depthwise weights [9][Cin] + bias [Cin] -> LDS (read back with ds_read_b128, no global latency per tap)
+  const int nW4 = (10 * p.Cin) >> 2;
+  for (int i = tid; i < nW4; i += 256)
+    *(f32x4*)&Ws[i * 4] = (i * 4 < 9 * p.Cin) ? *(const f32x4*)(p.wd + (long)i * 4)
+                                              : *(const f32x4*)(p.bd + ((long)i * 4 - 9 * p.Cin));
+  __syncthreads();
+
+  // phase 1: depthwise + shortcut.  Branch-free taps: all 9 loads of an item are issued back to back
+  // (addresses clamped into the map, out-of-range taps masked to zero afterwards).
   const int KC4 = p.Kpad >> 2;  // A columns (in float4) incl. zero padding
   for (int it = tid; it < TM * KC4; it += 256) {
     const int r = it / KC4, c4 = it - r * KC4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
-    const long m = m0 + r;
-    if (c4 < p.C4 && m < p.M) {
+    if (c4 < p.C4) {
+      long m = m0 + r;
+      m = m < p.M ? m : p.M - 1;  // tail rows recompute the last pixel; they are never stored
       const unsigned mm = (unsigned)m;
       const unsigned img = mm / (unsigned)p.OHW;
       const unsigned rem = mm - img * (unsigned)p.OHW;
       const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
       const int c = c4 * 4;
       const float* ib = p.in + (long)img * p.in_ns + c;
-      if (p.stride == 1) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 xv[9];
+      const int iy0 = p.stride == 1 ? oy - 1 : 2 * oy, ix0 = p.stride == 1 ? ox - 1 : 2 * ox;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = oy - 1 + ky;
-          if (iy < 0 || iy >= p.H) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = iy0 + ky;
+        const bool vy = (unsigned)iy < (unsigned)p.H;
+        const float* rowp = ib + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox - 1 + kx;
-            if (ix < 0 || ix >= p.W) continue;
-            const f32x4 x = *(const f32x4*)(ib + ((long)iy * p.W + ix) * p.in_ld);
-            const f32x4 wv = *(const f32x4*)(p.wd + (ky * 3 + kx) * p.Cin + c);
-            acc += x * wv;
-            if (ky == 1 && kx == 1) sc = x;
-          }
-        }
-      } else {
-        const float ninf = -__builtin_huge_valf();
-        sc = (f32x4){ninf, ninf, ninf, ninf};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = 2 * oy + ky;
-          if (iy >= p.H) continue;
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * ox + kx;
-            if (ix >= p.W) continue;
-            const f32x4 x = *(const f32x4*)(ib + ((long)iy * p.W + ix) * p.in_ld);
-            const f32x4 wv = *(const f32x4*)(p.wd + (ky * 3 + kx) * p.Cin + c);
-            acc += x * wv;
-            if (ky < 2 && kx < 2) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) sc[e] = fmaxf(sc[e], x[e]);
-            }
-          }
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ix0 + kx;
+          const bool v = vy && ((unsigned)ix < (unsigned)p.W);
+          const f32x4 x = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
+          xv[ky * 3 + kx] = v ? x : z;
         }
       }
-      acc += *(const f32x4*)(p.bd + c);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += xv[t] * *(const f32x4*)&Ws[t * p.Cin + c];
+      acc += *(const f32x4*)&Ws[9 * p.Cin + c];
+      if (p.stride == 1) {
+        sc = xv[4];  // centre tap = x itself
+      } else {
+        // taps (0..1, 0..1) are the 2x2 max-pool window (always inside the map: H, W even)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[e] = fmaxf(fmaxf(xv[0][e], xv[1][e]), fmaxf(xv[3][e], xv[4][e]));
+      }
     }
     *(f32x4*)&At[r * LDT + c4 * 4] = acc;
     if (c4 < p.C4) *(f32x4*)&St[r * LDS_ + c4 * 4] = sc;
   }
-  (void)items;
   __syncthreads();
 
   // phase 2: 1x1 conv on the MFMA pipe
@@ -176,7 +173,7 @@ size_t fp_blazeblock_lds_bytes(int Cin, int Cout) {
   const int Kpad = (int)fp_round_up(Cin, 8), Npad = (int)fp_round_up(Cout, 32);
   const int LDT = Kpad + 4;
   const size_t a = (size_t)TM * (LDT > Cout ? LDT : Cout);
-  return 4 * (a + (size_t)TM * (Cin + 4) + (size_t)Kpad * Npad);
+  return 4 * (a + (size_t)TM * (Cin + 4) + (size_t)Kpad * Npad + (size_t)10 * Cin);
 }
 
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s) {

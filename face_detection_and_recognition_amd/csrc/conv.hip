@@ -256,35 +256,44 @@ template <int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= p.total) return;
-  const int c4 = (int)(idx % p.C4);
-  const long m = idx / p.C4;
-  const int img = (int)(m / p.OHW);
-  const int pix = (int)(m - (long)img * p.OHW);
+  const unsigned uidx = (unsigned)idx;  // total < 2^31 (checked by the launcher)
+  const unsigned m = uidx / (unsigned)p.C4;
+  const int c4 = (int)(uidx - m * (unsigned)p.C4);
+  const unsigned img = m / (unsigned)p.OHW;
+  const int pix = (int)(m - img * (unsigned)p.OHW);
   const int oy = pix / p.OW, ox = pix - oy * p.OW;
   const int c = c4 * 4;
   const float* ibase = p.in + (long)img * p.in_ns + c;
+  const float* wbase = p.w + c;
+  // Branch-free taps: every load is issued (address clamped into the map) and masked afterwards, so the
+  // KS*KS activation loads and the weight loads go out back to back instead of one wait per tap.
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
 #pragma unroll
   for (int ky = 0; ky < KS; ++ky) {
-    const int iy = oy * p.stride - p.pad_t + ky;
-    if (iy < 0 || iy >= p.H) continue;
+    const int iy = iy0 + ky;
+    const bool vy = (unsigned)iy < (unsigned)p.H;
+    const int iyc = min(max(iy, 0), p.H - 1);
+    const float* rowp = ibase + (long)iyc * p.W * p.in_ld;
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
-      const int ix = ox * p.stride - p.pad_l + kx;
-      if (ix < 0 || ix >= p.W) continue;
-      const f32x4 x = *(const f32x4*)(ibase + ((long)iy * p.W + ix) * p.in_ld);
-      const f32x4 wv = *(const f32x4*)(p.w + (ky * KS + kx) * p.C + c);
+      const int ix = ix0 + kx;
+      const bool v = vy && ((unsigned)ix < (unsigned)p.W);
+      const int ixc = min(max(ix, 0), p.W - 1);
+      f32x4 x = *(const f32x4*)(rowp + (long)ixc * p.in_ld);
+      const f32x4 wv = *(const f32x4*)(wbase + (ky * KS + kx) * p.C);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      x = v ? x : z;
       acc += x * wv;
     }
   }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f}, sl = {0.f, 0.f, 0.f, 0.f};
+  if (p.scale) sc = *(const f32x4*)(p.scale + c);
+  if (p.bias) bi = *(const f32x4*)(p.bias + c);
+  if (p.act == FP_ACT_PRELU) sl = *(const f32x4*)(p.slope + c);
   f32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float v = acc[e];
-    if (p.scale) v *= p.scale[c + e];
-    if (p.bias) v += p.bias[c + e];
-    o[e] = apply_act(v, p.act, p.act == FP_ACT_PRELU ? p.slope[c + e] : 0.f);
-  }
+  for (int e = 0; e < 4; ++e) o[e] = apply_act(acc[e] * sc[e] + bi[e], p.act, sl[e]);
   *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c) = o;
 }
 
@@ -439,6 +448,7 @@ int fp_launch_dwconv(const fp_op& op, const float* weights, float* arena, hipStr
   a.act = op.act; a.OHW = op.OH * op.OW; a.C4 = op.Cin / 4;
   a.total = (long)op.N * a.OHW * a.C4;
   if (a.act == FP_ACT_PRELU && !a.slope) return FP_ERR_INVALID_ARG;
+  if (a.total >= (1L << 31)) return FP_ERR_UNSUPPORTED;  // 32-bit item decode in the kernel
   dim3 grid((unsigned)fp_ceil_div(a.total, 256)), block(256);
   switch (op.KH) {
     case 3: hipLaunchKernelGGL((dwconv_kernel<3>), grid, block, 0, s, a); break;

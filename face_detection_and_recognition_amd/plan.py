@@ -250,7 +250,7 @@ class PlanBuilder:
         """Mirror of fp_blazeblock_lds_bytes (csrc/blaze.hip): the fused kernel needs <= 64 KiB of LDS."""
         kpad, npad = round_up(cin_phys, 8), round_up(cout_phys, 32)
         a = 128 * max(kpad + 4, cout_phys)
-        return 4 * (a + 128 * (cin_phys + 4) + kpad * npad)
+        return 4 * (a + 128 * (cin_phys + 4) + kpad * npad + 10 * cin_phys)
 
     def blazeblock(self, x, wd, bd, wp, bp, out, stride):
         """Fused BlazeBlock (blazeface.py:12-47): dw3x3(stride) -> 1x1 -> + shortcut -> ReLU in one kernel."""

@@ -1,0 +1,58 @@
+"""Per-op timing of the two network plans with the timed executor (HIP events on the launch stream)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from face_detection_and_recognition_amd import workload as W  # noqa: E402
+from face_detection_and_recognition_amd import _lib as L  # noqa: E402
+
+
+def profile(plan, name, reps=10):
+    mask = bytes([1] * plan.n_ops)
+    ms = (ctypes.c_float * plan.n_ops)()
+    for _ in range(3):
+        plan.run()
+    torch.cuda.synchronize()
+    timers = [plan.new_timer() for _ in range(reps)]
+    for t in timers:
+        plan.run_timed(t, mask)
+    torch.cuda.synchronize()
+    for t in timers:
+        plan.accumulate(t, ms)
+        plan.destroy_timer(t)
+    tot = sum(ms) / reps
+    print(f"== {name}: {plan.n_ops} ops, {tot:.3f} ms/run")
+    for i in range(plan.n_ops):
+        op = plan.ops[i]
+        t = ms[i] / reps
+        gb = plan.algorithmic_bytes(i) / 1e9
+        fl = 0
+        if op.kind == L.OP_CONV:
+            fl = 2.0 * op.N * op.OH * op.OW * op.KH * op.KW * op.Cin * op.Cout
+        elif op.kind == L.OP_DWCONV:
+            fl = 2.0 * op.N * op.OH * op.OW * op.KH * op.KW * op.Cin
+        elif op.kind == L.OP_BLAZEBLOCK:
+            fl = 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
+        print(f"{i:3d} {plan.kernel_name(i):34s} {op.H:4d}x{op.W:<4d} {op.Cin:4d}->{op.Cout:<4d} k{op.KH} s{op.stride} "
+              f"{t * 1e3:9.1f} us {100 * t / tot:5.1f}%  {gb / (t * 1e-3 + 1e-12):8.0f} GB/s {fl / (t * 1e-3 + 1e-12) / 1e12:6.1f} TF/s")
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    NF = int(sys.argv[2]) if len(sys.argv) > 2 else 1088
+    dev = torch.device("cuda:0")
+    det = W.build_blazeface_back(dev)
+    emb = W.build_embedder(dev)
+    p = det.plan_for(B)
+    p.input.normal_()
+    profile(p, f"blazeface-back B={B}")
+    q = emb.plan_for(NF)
+    q.input.normal_()
+    profile(q, f"mobilefacenet N={NF}")
+
+
+if __name__ == "__main__":
+    main()
