@@ -32,6 +32,7 @@ struct ConvArgs {
   int act, res_mode;
   int K, Kpad, Npad, OHW;
   long M;
+  int vec_epi, res_C4;
 };
 
 constexpr int BM = 128;
@@ -50,8 +51,10 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 template <int NB, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
-  __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[(KC / 4) * BN * 4];
+  // one LDS array: A tile, then B tile; the vector epilogue reuses it as the output staging tile
+  __shared__ __attribute__((aligned(16))) float smem[BM * LDA + (KC / 4) * BN * 4];
+  float* As = smem;
+  float* Bs = smem + BM * LDA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -169,6 +172,81 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 
   // Epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  if (p.vec_epi) {
+    // Vector epilogue: acc*scale+bias goes through LDS (PW 32-column blocks per pass) so that every lane then
+    // owns 4 consecutive channels of one pixel: residual loads, activation and the output stores are 16-byte,
+    // fully coalesced accesses (256 B per row for PW = 2) instead of 4-byte stores in 128-B segments.
+    constexpr int PW = (NB == 4) ? 2 : 1;
+    constexpr int LDO = PW * 32 + 4;
+    constexpr int F4_PER_ROW = PW * 8;
+    float sc[NB], bi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + nb * 32 + lr;
+      const int nn = n < p.Cout ? n : 0;
+      sc[nb] = p.scale ? p.scale[nn] : 1.f;
+      bi[nb] = p.bias ? p.bias[nn] : 0.f;
+    }
+    const unsigned uOHW = (unsigned)p.OHW;
+    const unsigned img_b = (unsigned)m0 / uOHW;
+    const unsigned pix_b = (unsigned)m0 - img_b * uOHW;
+    const int act = p.act, res_mode = p.res_mode;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < NB / PW; ++pass) {
+      if (pass) __syncthreads();  // the previous pass has been read out
+#pragma unroll
+      for (int q = 0; q < PW; ++q) {
+        const int nb = pass * PW + q;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          smem[row * LDO + q * 32 + lr] = acc[nb][reg] * sc[nb] + bi[nb];
+        }
+      }
+      __syncthreads();
+      const int ncol0 = n0 + pass * PW * 32;
+      for (int f = tid; f < BM * F4_PER_ROW; f += 256) {
+        const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+        const long m = m0 + row;
+        const int n = ncol0 + c4 * 4;
+        if (m >= p.M || n >= p.Cout) continue;
+        unsigned img = img_b, pix = pix_b + (unsigned)row;
+        if (uOHW >= (unsigned)BM) {
+          if (pix >= uOHW) { pix -= uOHW; ++img; }
+        } else {
+          const unsigned qd = pix / uOHW;
+          img += qd;
+          pix -= qd * uOHW;
+        }
+        f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
+        f32x4 r = z4;
+        if (res_mode != FP_RES_NONE && n < p.res_C4) {
+          if (res_mode == FP_RES_POOL2_BEFORE_ACT) {
+            const unsigned oy = pix / (unsigned)p.OW, ox = pix - oy * (unsigned)p.OW;
+            const float* r0 = p.res + (long)img * p.res_ns + ((long)(2 * oy) * p.res_W + 2 * ox) * p.res_ld + n;
+            const float* r1 = r0 + (long)p.res_W * p.res_ld;
+            const f32x4 a0 = *(const f32x4*)r0, a1 = *(const f32x4*)(r0 + p.res_ld);
+            const f32x4 b0 = *(const f32x4*)r1, b1 = *(const f32x4*)(r1 + p.res_ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(a0[e], a1[e]), fmaxf(b0[e], b1[e]));
+          } else {
+            r = *(const f32x4*)(p.res + (long)img * p.res_ns + (long)pix * p.res_ld + n);
+          }
+        }
+        f32x4 sl = z4;
+        if (act == FP_ACT_PRELU) sl = *(const f32x4*)(p.slope + n);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (res_mode == FP_RES_ADD_AFTER_ACT) ? apply_act(v[e], act, sl[e]) + r[e]
+                                                    : apply_act(v[e] + r[e], act, sl[e]);
+        *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + n) = o;
+      }
+    }
+    return;
+  }
+  // Scalar epilogue (odd channel counts, interleaved outputs: heads, shuffle writes).
   // Per-column parameters are lane constants: fetch them once, before the store loop.
   float sc[NB], bi[NB], sl[NB];
   bool nv[NB];
@@ -405,6 +483,13 @@ int fp_launch_conv(const fp_op& op, const float* weights, float* arena, hipStrea
   if (a.act == FP_ACT_PRELU && !a.slope) return FP_ERR_INVALID_ARG;
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;  // 32-bit row decode in the kernel
   const bool vec = (op.Cin % 4 == 0) && (op.in_ld % 4 == 0) && (op.in_off % 4 == 0) && (op.in_ns % 4 == 0);
+  a.res_C4 = (int)fp_round_up(op.res_C, 4);
+  bool ve = op.out_cmul == 1 && op.Cout % 4 == 0 && op.out_ld % 4 == 0 && op.out_off % 4 == 0 && op.out_ns % 4 == 0 &&
+            (op.scale_off < 0 || op.scale_off % 4 == 0) && (op.bias_off < 0 || op.bias_off % 4 == 0) &&
+            (op.slope_off < 0 || op.slope_off % 4 == 0);
+  if (op.res_mode != FP_RES_NONE)
+    ve = ve && op.res_ld % 4 == 0 && op.res_off % 4 == 0 && op.res_ns % 4 == 0 && a.res_C4 <= op.res_ld;
+  a.vec_epi = ve ? 1 : 0;
   const int nblk32 = a.Npad / 32;
   int NB = 4;
   if (nblk32 % 4 == 0) NB = 4;
