@@ -1,0 +1,497 @@
+"""YOLOv5-face on MI355X: the reference's module classes, yaml-driven model builder and ``state_dict`` keys
+(face_detection_and_extraction/modules/yolov5_face/pytorch/models/{common,yolo,experimental}.py) compiled
+to a HIP plan.
+
+  Conv / fuse_conv_and_bn   common.py:39-55, utils/torch_utils.py:164-184  -> FP_OP_CONV (+BN affine or folded bias, SiLU)
+  StemBlock                 common.py:58-73
+  Bottleneck / C3           common.py:76-87, 111-124
+  ShuffleV2Block            common.py:21-31, 127-176 (BatchNorm stays live: Model.fuse only folds `Conv`)
+  SPP / Upsample / Concat   common.py:179-191, 235-242
+  Detect                    yolo.py:29-113  -> FP_OP_CONV heads + fp_yolo_decode
+  Model / parse_model       yolo.py:116-327 (the reference's parse_model is broken for its own yamls, SURVEY F5;
+                            this one resolves module names and nc/anchors from the spec directly)
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ...plan import CompiledPlan, PlanBuilder, View, bn_affine, cpad
+from ..params import BNParams, ConvParams, _NoCompute, npy
+
+# Architecture specs of the reference's in-tree yamls (y5/models/yolov5n.yaml, yolov5s.yaml, yolov5n-0.5.yaml):
+# [from, number, module, args] rows, same meaning as upstream.
+ANCHORS = [[4, 5, 8, 10, 13, 16], [23, 29, 43, 55, 73, 105], [146, 217, 231, 300, 335, 433]]
+_HEAD_N = [[-1, 1, "Conv", [128, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]], [[-1, 4], 1, "Concat", [1]],
+           [-1, 1, "C3", [128, False]], [-1, 1, "Conv", [128, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]],
+           [[-1, 2], 1, "Concat", [1]], [-1, 1, "C3", [128, False]], [-1, 1, "Conv", [128, 3, 2]],
+           [[-1, 11], 1, "Concat", [1]], [-1, 1, "C3", [128, False]], [-1, 1, "Conv", [128, 3, 2]],
+           [[-1, 7], 1, "Concat", [1]], [-1, 1, "C3", [128, False]], [[14, 17, 20], 1, "Detect", ["nc", "anchors"]]]
+_BACKBONE_N = [[-1, 1, "StemBlock", [32, 3, 2]], [-1, 1, "ShuffleV2Block", [128, 2]], [-1, 3, "ShuffleV2Block", [128, 1]],
+               [-1, 1, "ShuffleV2Block", [256, 2]], [-1, 7, "ShuffleV2Block", [256, 1]],
+               [-1, 1, "ShuffleV2Block", [512, 2]], [-1, 3, "ShuffleV2Block", [512, 1]]]
+SPECS = {
+    "yolov5n": dict(nc=1, depth_multiple=1.0, width_multiple=1.0, anchors=ANCHORS, backbone=_BACKBONE_N, head=_HEAD_N),
+    "yolov5n-0.5": dict(nc=1, depth_multiple=1.0, width_multiple=0.5, anchors=ANCHORS, backbone=_BACKBONE_N,
+                        head=_HEAD_N),
+    "yolov5s": dict(
+        nc=1, depth_multiple=0.33, width_multiple=0.35, anchors=ANCHORS,
+        backbone=[[-1, 1, "StemBlock", [64, 3, 2]], [-1, 3, "C3", [128]], [-1, 1, "Conv", [256, 3, 2]],
+                  [-1, 9, "C3", [256]], [-1, 1, "Conv", [512, 3, 2]], [-1, 9, "C3", [512]],
+                  [-1, 1, "Conv", [1024, 3, 2]], [-1, 1, "SPP", [1024, [3, 5, 7]]], [-1, 3, "C3", [1024, False]]],
+        head=[[-1, 1, "Conv", [512, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]], [[-1, 5], 1, "Concat", [1]],
+              [-1, 3, "C3", [512, False]], [-1, 1, "Conv", [256, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]],
+              [[-1, 3], 1, "Concat", [1]], [-1, 3, "C3", [256, False]], [-1, 1, "Conv", [256, 3, 2]],
+              [[-1, 13], 1, "Concat", [1]], [-1, 3, "C3", [512, False]], [-1, 1, "Conv", [512, 3, 2]],
+              [[-1, 9], 1, "Concat", [1]], [-1, 3, "C3", [1024, False]], [[16, 19, 22], 1, "Detect", ["nc", "anchors"]]]),
+}
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def autopad(k, p=None):
+    """common.py:14-18."""
+    return k // 2 if p is None else p
+
+
+def fuse_conv_and_bn_arrays(w, bn):
+    """fuse_conv_and_bn (utils/torch_utils.py:164-184) in torch fp32, same operation order."""
+    w_conv = w.clone().view(w.shape[0], -1)
+    w_bn = torch.diag(bn.weight.div(torch.sqrt(bn.eps + bn.running_var)))
+    fw = torch.mm(w_bn, w_conv).view(w.shape)
+    b_conv = torch.zeros(w.shape[0])
+    b_bn = bn.bias - bn.weight.mul(bn.running_mean).div(torch.sqrt(bn.running_var + bn.eps))
+    fb = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn
+    return fw, fb
+
+
+def _bn_sb(bn):
+    return bn_affine(npy(bn.weight), npy(bn.bias), npy(bn.running_mean), npy(bn.running_var), bn.eps)
+
+
+class Conv(_NoCompute):
+    """conv(no bias) -> BN -> SiLU; after fuse(): conv(with bias) -> SiLU (common.py:39-55)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        assert g == 1
+        self.c1, self.c2, self.k, self.s, self.p = c1, c2, k, s, autopad(k, p)
+        self.conv = ConvParams(c1, c2, k, s, self.p, bias=False)
+        self.bn = BNParams(c2, eps=1e-3)      # initialize_weights sets eps=1e-3 (utils/torch_utils.py:102-104)
+        self.act = act
+
+    def fuse(self):
+        if self.bn is None:
+            return
+        fw, fb = fuse_conv_and_bn_arrays(self.conv.weight.detach().cpu(), self.bn.cpu())
+        dev = self.conv.weight.device
+        self.conv.weight = nn.Parameter(fw.to(dev), requires_grad=False)
+        self.conv.bias = nn.Parameter(fb.to(dev), requires_grad=False)
+        self.bn = None
+
+    def make_fused_structure(self):
+        if self.bn is not None:
+            self.conv.bias = nn.Parameter(torch.zeros(self.c2, device=self.conv.weight.device), requires_grad=False)
+            self.bn = None
+
+    def emit(self, pb, x, out=None, res=None):
+        OH = (x.H + 2 * self.p - self.k) // self.s + 1
+        OW = (x.W + 2 * self.p - self.k) // self.s + 1
+        if out is None:
+            out = pb.new_buf(OH, OW, self.c2).view()
+        kw = dict(stride=self.s, pad=(self.p, self.p), act=L.ACT_SILU if self.act else L.ACT_NONE)
+        if self.bn is None:
+            kw["bias"] = npy(self.conv.bias)
+        else:
+            kw["scale"], kw["bias"] = _bn_sb(self.bn)
+        if res is not None:
+            kw.update(res=res, res_mode=L.RES_ADD_AFTER_ACT)
+        pb.conv(x, npy(self.conv.weight), out, **kw)
+        return out
+
+
+class StemBlock(_NoCompute):
+    """common.py:58-73."""
+
+    def __init__(self, c1, c2, k=3, s=2, p=None, g=1, act=True):
+        super().__init__()
+        self.c2 = c2
+        self.stem_1 = Conv(c1, c2, k, s, p, g, act)
+        self.stem_2a = Conv(c2, c2 // 2, 1, 1, 0)
+        self.stem_2b = Conv(c2 // 2, c2, 3, 2, 1)
+        self.stem_3 = Conv(c2 * 2, c2, 1, 1, 0)
+
+    def emit(self, pb, x):
+        s1 = self.stem_1.emit(pb, x)
+        a = self.stem_2a.emit(pb, s1)
+        OH, OW = math.ceil(s1.H / 2), math.ceil(s1.W / 2)            # MaxPool2d(2, 2, ceil_mode=True)
+        cat = pb.new_buf(OH, OW, 2 * self.c2)
+        self.stem_2b.emit(pb, a, out=cat.view(0, self.c2))
+        pb.maxpool(s1, cat.view(self.c2, self.c2), 2, 2, 0)
+        pb.free(a.buf)
+        pb.free(s1.buf)
+        y = self.stem_3.emit(pb, cat.view())
+        pb.free(cat)
+        return y
+
+
+class Bottleneck(_NoCompute):
+    """common.py:76-87."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1)
+        self.add = shortcut and c1 == c2
+
+    def emit(self, pb, x, out=None):
+        t = self.cv1.emit(pb, x)
+        y = self.cv2.emit(pb, t, out=out, res=x if self.add else None)
+        pb.free(t.buf)
+        return y
+
+
+class C3(_NoCompute):
+    """common.py:111-124: cv3(cat(m(cv1(x)), cv2(x)))."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.c_, self.c2 = c_, c2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    def emit(self, pb, x):
+        assert self.c_ % 4 == 0, "C3 hidden width must be a multiple of 4 for the in-place concat"
+        cat = pb.new_buf(x.H, x.W, 2 * self.c_)
+        t = self.cv1.emit(pb, x)
+        for i, b in enumerate(self.m):
+            last = i == len(self.m) - 1
+            y = b.emit(pb, t, out=cat.view(0, self.c_) if last else None)
+            pb.free(t.buf)
+            t = y
+        self.cv2.emit(pb, x, out=cat.view(self.c_, self.c_))
+        out = self.cv3.emit(pb, cat.view())
+        pb.free(cat)
+        return out
+
+
+class _Tag(_NoCompute):
+    """Parameter-free placeholder (nn.SiLU slots in ShuffleV2Block branches) so child indices match."""
+
+
+class ShuffleV2Block(_NoCompute):
+    """common.py:127-176 + channel_shuffle (:21-31).  The concat + shuffle is pure addressing: the two halves are
+    written interleaved (out_cmul = 2) straight into the output tensor."""
+
+    def __init__(self, inp, oup, stride):
+        super().__init__()
+        self.stride, self.inp, self.oup = stride, inp, oup
+        bf = oup // 2
+        self.bf = bf
+        assert stride != 1 or inp == bf << 1
+        if stride > 1:
+            self.branch1 = nn.Sequential(ConvParams(inp, inp, 3, stride, 1, groups=inp, bias=False), BNParams(inp, eps=1e-3),
+                                         ConvParams(inp, bf, 1, 1, 0, bias=False), BNParams(bf, eps=1e-3), _Tag())
+        else:
+            self.branch1 = nn.Sequential()
+        c_in2 = inp if stride > 1 else bf
+        self.branch2 = nn.Sequential(ConvParams(c_in2, bf, 1, 1, 0, bias=False), BNParams(bf, eps=1e-3), _Tag(),
+                                     ConvParams(bf, bf, 3, stride, 1, groups=bf, bias=False), BNParams(bf, eps=1e-3),
+                                     ConvParams(bf, bf, 1, 1, 0, bias=False), BNParams(bf, eps=1e-3), _Tag())
+
+    def emit(self, pb, x):
+        s = self.stride
+        OH, OW = (x.H + 2 - 3) // s + 1, (x.W + 2 - 3) // s + 1
+        out = pb.new_buf(OH, OW, self.oup)
+        even, odd = out.view(0, self.bf, cmul=2), out.view(1, self.bf, cmul=2)
+        b2 = self.branch2
+        if s == 1:
+            pb.copy(View(x.buf, x.coff, self.bf), even)                                  # x1 passthrough
+            x2 = View(x.buf, x.coff + self.bf, self.bf)
+        else:
+            b1 = self.branch1
+            t = pb.new_buf(OH, OW, self.inp)
+            sc, bi = _bn_sb(b1[1])
+            pb.dwconv(x, npy(b1[0].weight), t.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
+            sc, bi = _bn_sb(b1[3])
+            pb.conv(t.view(), npy(b1[2].weight), even, scale=sc, bias=bi, act=L.ACT_SILU)
+            pb.free(t)
+            x2 = x
+        t1 = pb.new_buf(x.H, x.W, self.bf)
+        sc, bi = _bn_sb(b2[1])
+        pb.conv(x2, npy(b2[0].weight), t1.view(), scale=sc, bias=bi, act=L.ACT_SILU)
+        t2 = pb.new_buf(OH, OW, self.bf)
+        sc, bi = _bn_sb(b2[4])
+        pb.dwconv(t1.view(), npy(b2[3].weight), t2.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
+        pb.free(t1)
+        sc, bi = _bn_sb(b2[6])
+        pb.conv(t2.view(), npy(b2[5].weight), odd, scale=sc, bias=bi, act=L.ACT_SILU)
+        pb.free(t2)
+        return out.view()
+
+
+class SPP(_NoCompute):
+    """common.py:179-191."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        c_ = c1 // 2
+        self.c_, self.k = c_, tuple(k)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+
+    def emit(self, pb, x):
+        assert self.c_ % 4 == 0
+        cat = pb.new_buf(x.H, x.W, self.c_ * (len(self.k) + 1))
+        first = cat.view(0, self.c_)
+        self.cv1.emit(pb, x, out=first)
+        for i, k in enumerate(self.k):
+            pb.maxpool(first, cat.view(self.c_ * (i + 1), self.c_), k, 1, k // 2)
+        y = self.cv2.emit(pb, cat.view())
+        pb.free(cat)
+        return y
+
+
+class Upsample(_NoCompute):
+    def emit(self, pb, x):
+        out = pb.new_buf(2 * x.H, 2 * x.W, x.C)
+        return pb.upsample2x(x, out.view(0, x.C))
+
+
+class Concat(_NoCompute):
+    """common.py:235-242 (dimension 1)."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def emit(self, pb, xs):
+        C = sum(v.C for v in xs)
+        out = pb.new_buf(xs[0].H, xs[0].W, C)
+        off = 0
+        for v in xs:
+            assert v.C % 4 == 0
+            pb.copy(v, out.view(off, v.C))
+            off += v.C
+        return out.view()
+
+
+class Detect(_NoCompute):
+    """yolo.py:29-113: per level a 1x1 conv to na*(nc+5+10) channels, then the inference decode."""
+    stride = None
+
+    def __init__(self, nc=1, anchors=(), ch=()):
+        super().__init__()
+        self.nc = nc
+        self.no = nc + 5 + 10
+        self.nl = len(anchors)
+        self.na = len(anchors[0]) // 2
+        a = torch.tensor(anchors).float().view(self.nl, -1, 2)
+        self.register_buffer("anchors", a)
+        self.register_buffer("anchor_grid", a.clone().view(self.nl, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(ConvParams(x, self.no * self.na, 1, bias=True) for x in ch)
+
+
+class Model(nn.Module):
+    """yolo.py:116-257.  ``forward(x)``: (b, 3, H, W) float in [0, 1], H and W multiples of 32 ->
+    ``(z, heads)`` with z (b, sum(3*ny*nx), 16) decoded predictions, like the reference in eval mode."""
+
+    def __init__(self, cfg="yolov5s", ch=3, nc=None):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = cfg
+        else:
+            name = os.path.basename(str(cfg))
+            for ext in (".yaml", ".yml"):
+                if name.endswith(ext):
+                    name = name[:-len(ext)]
+            if name not in SPECS:
+                raise FileNotFoundError(f"unknown YOLOv5-face config {cfg!r}; known: {sorted(SPECS)}")
+            self.yaml = SPECS[name]
+        if nc and nc != self.yaml["nc"]:
+            self.yaml = dict(self.yaml, nc=nc)
+        self.model, self.save = parse_model(self.yaml, [ch])
+        m = self.model[-1]
+        # strides of the three levels (the reference measures them with a dry forward pass, yolo.py:140-146)
+        m.stride = torch.tensor([8., 16., 32.])
+        m.anchors = m.anchors / m.stride.view(-1, 1, 1)
+        self.stride = m.stride
+        self.names = [str(i) for i in range(self.yaml["nc"])]
+        self._plans = {}
+
+    # ---- reference API ----
+    def fuse(self):
+        for mod in self.model.modules():
+            if isinstance(mod, Conv):
+                mod.fuse()
+        self._plans = {}
+        return self
+
+    def float(self):
+        return self
+
+    def load_state_dict(self, sd, *a, **k):
+        if any(key.endswith(".conv.bias") for key in sd) and not any(".stem_1.bn." in key for key in sd):
+            for mod in self.model.modules():            # checkpoint of a fused model (Conv without bn)
+                if isinstance(mod, Conv):
+                    mod.make_fused_structure()
+        out = super().load_state_dict(sd, *a, **k)
+        self._plans = {}
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._plans = {}
+        return out
+
+    def _device(self):
+        return self.model[-1].m[0].weight.device
+
+    # ---- plan ----
+    def _emit(self, N, H=640, W=640):
+        assert H % 32 == 0 and W % 32 == 0
+        pb = PlanBuilder(N)
+        inp = pb.new_buf(H, W, 3)
+        det = self.model[-1]
+        # liveness: layer j's output dies after the last layer that reads it
+        last_use = {}
+        for m in self.model:
+            for j in ([m.f] if isinstance(m.f, int) else m.f):
+                src = m.i - 1 if j == -1 else j
+                if src >= 0:
+                    last_use[src] = m.i
+        outs = {}
+        heads = []
+        for m in self.model:
+            fs = [m.f] if isinstance(m.f, int) else m.f
+            ins = [inp.view() if (j == -1 and m.i == 0) else outs[m.i - 1 if j == -1 else j] for j in fs]
+            if isinstance(m, Detect):
+                for src, conv in zip(ins, m.m):
+                    hb = pb.new_buf(src.H, src.W, det.no * det.na)
+                    pb.conv(src, npy(conv.weight), hb.view(0, det.no * det.na), bias=npy(conv.bias))
+                    heads.append(hb)
+                break
+            xin = ins if isinstance(m, Concat) else ins[0]
+            if isinstance(m, nn.Sequential):
+                y = xin
+                for sub in m:
+                    y2 = sub.emit(pb, y)
+                    if y is not xin:
+                        pb.free(y.buf)
+                    y = y2
+            else:
+                y = m.emit(pb, xin)
+            outs[m.i] = y
+            for j, lu in last_use.items():
+                if lu == m.i and j in outs:
+                    pb.free(outs[j].buf)
+        n_rows = sum(det.na * hb.H * hb.W for hb in heads)
+        z_off, _ = pb.new_raw(n_rows * det.no)
+        return pb, inp, heads, z_off, n_rows
+
+    def _build(self, N, H, W):
+        pb, inp, heads, z_off, n_rows = self._emit(N, H, W)
+        plan = CompiledPlan(pb, self._device())
+        plan.input = plan.buf_tensor(inp, N)
+        plan.heads = [plan.buf_tensor(hb, N) for hb in heads]
+        plan.z = plan.arena[z_off: z_off + N * n_rows * 16].view(N, n_rows, 16)
+        plan.n_rows = n_rows
+        return plan
+
+    def plan_for(self, N, H=640, W=640):
+        key = (N, H, W)
+        if key not in self._plans:
+            if self._device().type != "cuda":
+                raise L.FacepathError("YOLOv5-face runs only on a HIP device (model.to('cuda')); there is no CPU path")
+            self._plans[key] = self._build(N, H, W)
+        return self._plans[key]
+
+    def run_plan(self, plan):
+        """Forward + Detect decode on whatever is in plan.input.  Returns z (N, n_rows, 16)."""
+        plan.run()
+        det = self.model[-1]
+        lib = L.load()
+        dev = self._device()
+        row = 0
+        ag = det.anchor_grid.view(det.nl, det.na, 2).cpu().numpy()
+        for lvl, h in enumerate(plan.heads):
+            N, ny, nx, _ = h.shape
+            anc = (L.C.c_float * 6)(*[float(v) for v in ag[lvl].reshape(-1)])
+            L.check(lib.fp_yolo_decode(L.ptr(h), N, ny, nx, det.na, float(det.stride[lvl]), anc, L.ptr(plan.z),
+                                       plan.n_rows * 16, row, L.current_stream(dev)), "fp_yolo_decode")
+            row += det.na * ny * nx
+        return plan.z
+
+    def forward(self, x, augment=False, profile=False):
+        b, _, H, W = x.shape
+        plan = self.plan_for(b, H, W)
+        plan.input[..., :3].copy_(x.to(self._device(), torch.float32).permute(0, 2, 3, 1))
+        plan.input[..., 3:].zero_()
+        z = self.run_plan(plan)
+        det = self.model[-1]
+        heads = [h.view(b, h.shape[1], h.shape[2], det.na, det.no).permute(0, 3, 1, 2, 4) for h in plan.heads]
+        return z, heads
+
+
+def parse_model(d, ch):
+    """yolo.py:260-327 with names resolved from this module (fixes SURVEY F5)."""
+    table = {"Conv": Conv, "StemBlock": StemBlock, "C3": C3, "ShuffleV2Block": ShuffleV2Block, "SPP": SPP,
+             "Bottleneck": Bottleneck, "Concat": Concat, "nn.Upsample": Upsample, "Detect": Detect}
+    anchors, nc, gd, gw = d["anchors"], d["nc"], d["depth_multiple"], d["width_multiple"]
+    na = len(anchors[0]) // 2
+    no = na * (nc + 5)
+    layers, save, c2 = [], [], ch[-1]
+    ch = list(ch)
+    for i, (f, n, mname, args) in enumerate(d["backbone"] + d["head"]):
+        m = table[mname]
+        args = [nc if a == "nc" else anchors if a == "anchors" else a for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n
+        if m in (Conv, Bottleneck, SPP, C3, ShuffleV2Block, StemBlock):
+            c1, c2 = ch[f], args[0]
+            c2 = make_divisible(c2 * gw, 8) if c2 != no else c2
+            args = [c1, c2, *args[1:]]
+            if m is C3:
+                args.insert(2, n)
+                n = 1
+        elif m is Concat:
+            c2 = sum(ch[-1 if x == -1 else x + 1] for x in f)
+        elif m is Detect:
+            args.append([ch[x + 1] for x in f])
+        elif m is Upsample:
+            args = []
+            c2 = ch[f]
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*[m(*args) for _ in range(n)]) if n > 1 else m(*args)
+        m_.i, m_.f, m_.type = i, f, mname
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+def attempt_load(weights, map_location=None, cfg=None):
+    """experimental.py:117-140.  The reference unpickles a whole Model object (weights_only=False); this loader
+    only accepts data: a ``state_dict`` (or {'state_dict': ...} / {'model': state_dict}) read with
+    ``weights_only=True``; the architecture comes from ``cfg`` or the file name (yolov5n / yolov5s / yolov5n-0.5)."""
+    w = weights[0] if isinstance(weights, (list, tuple)) else weights
+    ck = torch.load(w, map_location="cpu", weights_only=True)
+    sd = ck.get("state_dict", ck.get("model", ck)) if isinstance(ck, dict) else ck
+    if not isinstance(sd, dict):
+        raise NotImplementedError("pickled Model checkpoints are not loaded (executes code); export its state_dict()")
+    if cfg is None:
+        base = os.path.basename(str(w)).lower()
+        cfg = "yolov5n-0.5" if "n-0.5" in base or "n0.5" in base else "yolov5n" if "yolov5n" in base else "yolov5s"
+    model = Model(cfg)
+    model.load_state_dict(sd)
+    dev = "cuda" if map_location is None else str(map_location).replace("hip", "cuda")
+    return model.to(dev).fuse()

@@ -256,3 +256,95 @@ def test_cosine_filter_ragged_and_large(dev):
         # the argmax may differ only where two scores tie within rounding
         bad = a != ra
         assert np.all(np.abs(Smat[np.arange(M), a][bad] - rb[bad]) < 1e-5)
+
+
+# ------------------------------------------------------------------ YOLOv5-face
+def _yolo(name, dev, seed, fuse):
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model
+    m = Model(name)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+    if fuse:
+        m.fuse()
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("name", ["yolov5n", "yolov5s"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_yolo_forward_vs_reference_golden(dev, name, fuse):
+    g = golden(f"{name}_forward")
+    m = _yolo(name, dev, int(g["seed"]), fuse)
+    z, heads = m(torch.from_numpy(g["x"]))
+    torch.cuda.synchronize()
+    for i, h in enumerate(heads):
+        assert rel_err(h.cpu().numpy(), g[f"head{i}"]) < 1e-4
+    assert rel_err(z.cpu().numpy(), g["z"]) < 1e-4
+
+
+def test_yolo_decode_and_wnms_vs_reference_golden(dev):
+    from face_detection_and_recognition_amd.modules.yolov5_face.general import (conv_strides_to_anchors,
+                                                                                   w_non_max_suppression)
+    g = golden("yolo_decode_wnms")
+    z = conv_strides_to_anchors([g[f"head{i}"] for i in range(3)], dev)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(z.cpu().numpy(), g["z"], rtol=2e-6, atol=2e-6)        # expf vs torch sigmoid
+    out = w_non_max_suppression(torch.from_numpy(g["pred"]).to(dev), 1, 0.4, 0.3)
+    for i, o in enumerate(out):
+        np.testing.assert_array_equal(o.cpu().numpy(), g[f"wnms{i}"])                # bit-exact keep set + rows
+
+
+def test_yolo_nms_face_keep_indices_bit_exact(dev):
+    from face_detection_and_recognition_amd.modules.yolov5_face.general import nms_face_device
+    from oracle import yolo_ref
+    rng = np.random.default_rng(8)
+    B, n = 5, 3000
+    pred = np.zeros((B, n, 16), np.float32)
+    pred[..., 0:2] = np.round(rng.uniform(0, 640, (B, n, 2)) / 24) * 24 + rng.normal(0, 2, (B, n, 2))
+    pred[..., 2:4] = rng.uniform(16, 120, (B, n, 2))
+    pred[..., 4] = rng.uniform(0, 1, (B, n))
+    pred[..., 5:15] = rng.uniform(0, 640, (B, n, 10))
+    pred[..., 15] = rng.uniform(0.3, 1, (B, n))
+    pred[4, :, 4] = 0.0                                         # image with no candidates
+    pred[3, 10:, 4] = 0.0                                       # image with a handful
+    out, cnt, keep, over = nms_face_device(torch.from_numpy(pred).to(dev), 0.4, 0.5)
+    torch.cuda.synchronize()
+    ref_out, ref_idx = yolo_ref.non_max_suppression_face(pred, 0.4, 0.5)
+    assert over.cpu().numpy().sum() == 0
+    for i in range(B):
+        k = int(cnt[i])
+        assert k == len(ref_idx[i])
+        np.testing.assert_array_equal(keep[i, :k].cpu().numpy(), ref_idx[i].numpy())     # bit-exact kept indices
+        np.testing.assert_array_equal(out[i, :k].cpu().numpy(), ref_out[i].numpy())
+
+
+def test_yolo_pipeline_matches_oracle_end_to_end(dev):
+    """detect_face_yolov5_face path on a 576x1024 frame: letterbox -> yolov5n -> decode -> NMS, vs the oracle."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import inference_pytorch_model_yolov5_face
+    from face_detection_and_recognition_amd.modules.yolov5_face.model import YOLOV5FaceModel
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import SPECS
+    from oracle import yolo_ref
+    m = _yolo("yolov5n", dev, 77, True)
+    rng = np.random.default_rng(2)
+    frame = rng.integers(0, 256, (576, 1024, 3), dtype=np.uint8)
+    lb = image_ref.pad_resize_image(frame[..., ::-1], (640, 640))
+    x = torch.from_numpy(image_ref.yolo_lut()[lb]).permute(2, 0, 1).unsqueeze(0)
+    # calibrate the objectness bias (random weights) so that ~80 of the 25200 anchors pass conf 0.4
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        z0, _ = yolo_ref.forward(SPECS["yolov5n"], sd, x)
+        obj = z0[0, :, 4].clamp(1e-6, 1 - 1e-6)
+        logit = torch.log(obj / (1 - obj))
+        delta = float(np.log(0.4 / 0.6) - torch.sort(logit, descending=True)[0][80]) + 0.05
+        for conv in m.model[-1].m:
+            conv.bias.view(3, 16)[:, 4] += delta
+            conv.bias.view(3, 16)[:, 15] += 6.0
+    m._plans = {}
+    model = YOLOV5FaceModel(m, 0.4, 0.0, inference_pytorch_model_yolov5_face, (640, 640))
+    dets = model(frame)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        z, _ = yolo_ref.forward(SPECS["yolov5n"], sd, x)
+    ref, _ = yolo_ref.non_max_suppression_face(z, 0.4, 0.5)
+    ref = ref[0].numpy()
+    assert len(dets) == len(ref) and len(ref) > 0
+    np.testing.assert_allclose(dets[:, :4] * 640, ref[:, :4], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(dets[:, 4], ref[:, 4], rtol=0, atol=1e-4)

@@ -89,3 +89,45 @@ def test_resize_oracle_properties():
     out = image_ref.pad_resize_image(np.zeros((576, 1024, 3), np.uint8), (256, 256))
     assert out.shape == (256, 256, 3) and np.all(out[:56] == 125) and np.all(out[56:200] == 0) and np.all(out[200:] == 125)
     assert image_ref.letterbox_geometry(1024, 576, 640, 640) == (640, 360, 0, 140)
+
+
+def test_yolo_oracle_matches_reference():
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model, SPECS
+    from oracle import yolo_ref
+    for name in ("yolov5n", "yolov5s"):
+        g = golden(f"{name}_forward")
+        sd = synth_state_dict(Model(name).state_dict(), int(g["seed"]))
+        with torch.no_grad():
+            z, heads = yolo_ref.forward(SPECS[name], sd, torch.from_numpy(g["x"]))
+        for i, h in enumerate(heads):                       # the golden ran the reference AFTER Model.fuse()
+            np.testing.assert_allclose(h.numpy(), g[f"head{i}"], rtol=0, atol=2e-5)
+        assert np.abs(z.numpy() - g["z"]).max() <= 1e-5 * np.abs(g["z"]).max()
+    g = golden("yolo_decode_wnms")
+    anchors = [np.asarray(a, np.float32).reshape(3, 2) for a in SPECS["yolov5n"]["anchors"]]
+    z = yolo_ref.detect_decode([torch.from_numpy(g[f"head{i}"]) for i in range(3)], anchors)
+    np.testing.assert_array_equal(z.numpy(), g["z"])        # conv_strides_to_anchors (pure reference)
+    for i, o in enumerate(yolo_ref.w_non_max_suppression(g["pred"], 0.4, 0.3)):
+        np.testing.assert_array_equal(o.numpy(), g[f"wnms{i}"])   # w_non_max_suppression (pure reference)
+    gi = golden("yolo_box_iou")
+    b = torch.from_numpy(gi["boxes"])
+    np.testing.assert_array_equal(yolo_ref.box_iou(b, b).numpy(), gi["iou"])
+
+
+def test_nms_restatement_consistent_with_reference_box_iou():
+    # torchvision.ops.nms is absent (parity unpinned); its restatement must agree with the reference's own
+    # pure-torch box_iou on which boxes suppress which.
+    from oracle import yolo_ref
+    rng = np.random.default_rng(4)
+    xy = rng.uniform(0, 200, (300, 2)); wh = rng.uniform(10, 80, (300, 2))
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32))
+    scores = torch.from_numpy(rng.uniform(0, 1, 300).astype(np.float32))
+    keep = yolo_ref.nms(boxes, scores, 0.5).numpy()
+    iou = yolo_ref.box_iou(boxes, boxes).numpy()
+    kept = set(keep.tolist())
+    order = np.argsort(-scores.numpy(), kind="stable")
+    for a_i, a in enumerate(keep):                           # kept boxes do not suppress each other
+        for b_ in keep[a_i + 1:]:
+            assert not iou[a, b_] > 0.5
+    for j in order:                                          # every dropped box is covered by a better kept one
+        if j not in kept:
+            assert any(iou[k, j] > 0.5 and scores[k] >= scores[j] for k in kept)
