@@ -332,7 +332,12 @@ struct DwArgs {
 
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware block order (blocks b, b+8, ... share an XCD): each XCD walks a contiguous range of the flattened
+  // (pixel, channel-group) space, so the rows a 3x3 window shares with its vertical neighbours are hits in that
+  // XCD's L2 instead of HBM re-fetches by another XCD (measured: FETCH_SIZE 2x the tensor without this).
+  const int nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8, xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+  const long idx = (long)vb * 256 + threadIdx.x;
   if (idx >= p.total) return;
   const unsigned uidx = (unsigned)idx;  // total < 2^31 (checked by the launcher)
   const unsigned m = uidx / (unsigned)p.C4;
@@ -373,6 +378,67 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs p) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = apply_act(acc[e] * sc[e] + bi[e], p.act, sl[e]);
   *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c) = o;
+}
+
+// Depthwise 3x3, 4 adjacent output columns per lane.  The generic kernel above issues 18 vector loads per output
+// float4 (9 taps + 9 weights) and is bound by the L1/TA rate, not by HBM.  Here a lane owns (row, 4 output
+// columns, 4 channels): the 3 x (3*S+3) input window is loaded once (sliding-window reuse between the 4 outputs)
+// and the 9 weight vectors stay in registers: 6.75 (S=1) / 9 (S=2) loads per output.  Lanes run over the channel
+// groups first, so every load is still a contiguous 16*C4-byte run per pixel.
+template <int S>
+__global__ __launch_bounds__(256) void dwconv3_row_kernel(DwArgs p, int OWG, long total_items) {
+  constexpr int P = 4;
+  constexpr int WIN = (P - 1) * S + 3;
+  const int nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8, xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+  const long idx = (long)vb * 256 + threadIdx.x;
+  if (idx >= total_items) return;
+  unsigned u = (unsigned)idx;
+  const int c4 = (int)(u % (unsigned)p.C4); u /= (unsigned)p.C4;
+  const int xg = (int)(u % (unsigned)OWG); u /= (unsigned)OWG;
+  const int oy = (int)(u % (unsigned)p.OH);
+  const unsigned img = u / (unsigned)p.OH;
+  const int c = c4 * 4;
+  const int ox0 = xg * P;
+  const float* ibase = p.in + (long)img * p.in_ns + c;
+  f32x4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)(p.w + t * p.C + c);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[P] = {z, z, z, z};
+  const int iy0 = oy * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = iy0 + ky;
+    const bool vy = (unsigned)iy < (unsigned)p.H;
+    const float* rowp = ibase + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+    f32x4 x[WIN];
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+      const int ix = ix0 + j;
+      const bool v = vy && ((unsigned)ix < (unsigned)p.W);
+      const f32x4 t = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
+      x[j] = v ? t : z;
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[q] += x[q * S + kx] * w[ky * 3 + kx];
+  }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = z, sl = z;
+  if (p.scale) sc = *(const f32x4*)(p.scale + c);
+  if (p.bias) bi = *(const f32x4*)(p.bias + c);
+  if (p.act == FP_ACT_PRELU) sl = *(const f32x4*)(p.slope + c);
+  float* obase = p.out + (long)img * p.out_ns + ((long)oy * p.OW + ox0) * p.out_ld + c;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    if (ox0 + q < p.OW) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = apply_act(acc[q][e] * sc[e] + bi[e], p.act, sl[e]);
+      *(f32x4*)(obase + (long)q * p.out_ld) = o;
+    }
+  }
 }
 
 // Max pooling (nn.MaxPool2d: y5/models/common.py:64,186-187; padding behaves as -inf).
@@ -535,6 +601,15 @@ int fp_launch_dwconv(const fp_op& op, const float* weights, float* arena, hipStr
   if (a.act == FP_ACT_PRELU && !a.slope) return FP_ERR_INVALID_ARG;
   if (a.total >= (1L << 31)) return FP_ERR_UNSUPPORTED;  // 32-bit item decode in the kernel
   dim3 grid((unsigned)fp_ceil_div(a.total, 256)), block(256);
+  if (op.KH == 3 && (op.stride == 1 || op.stride == 2)) {
+    const int OWG = (op.OW + 3) / 4;
+    const long items = (long)op.N * op.OH * OWG * a.C4;
+    dim3 g2((unsigned)fp_ceil_div(items, 256));
+    if (op.stride == 1) hipLaunchKernelGGL((dwconv3_row_kernel<1>), g2, block, 0, s, a, OWG, items);
+    else hipLaunchKernelGGL((dwconv3_row_kernel<2>), g2, block, 0, s, a, OWG, items);
+    FP_CHECK_LAUNCH();
+    return FP_OK;
+  }
   switch (op.KH) {
     case 3: hipLaunchKernelGGL((dwconv_kernel<3>), grid, block, 0, s, a); break;
     case 5: hipLaunchKernelGGL((dwconv_kernel<5>), grid, block, 0, s, a); break;

@@ -380,6 +380,8 @@ def op_kernel_name(op):
         nb = 4 if npad % 4 == 0 else 3 if npad % 3 == 0 else 2 if npad % 2 == 0 else 1 if npad == 1 else 4
         vec = op.Cin % 4 == 0 and op.in_ld % 4 == 0 and op.in_off % 4 == 0 and op.in_ns % 4 == 0
         return f"conv_igemm_kernel<{nb}, {'true' if vec else 'false'}>"
+    if op.kind == L.OP_DWCONV and op.KH == 3 and op.stride in (1, 2):
+        return f"dwconv3_row_kernel<{op.stride}>"
     return {L.OP_DWCONV: f"dwconv_kernel<{op.KH}>", L.OP_MAXPOOL: "maxpool_kernel",
             L.OP_UPSAMPLE2X: "upsample2x_kernel", L.OP_COPY: "copy_kernel", L.OP_L2NORM: "l2norm_kernel",
             L.OP_BLAZEBLOCK: "blazeblock_kernel"}.get(op.kind, "?")

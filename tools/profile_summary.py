@@ -1,0 +1,64 @@
+"""Condense rocprofv3 outputs (kernel stats CSV + the two PMC passes) into profiles/<tag>_*.
+
+  python tools/profile_summary.py r01 gpurun_out/prof_bench gpurun_out/pmc_fetch gpurun_out/pmc_write
+
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --kernel-trace --stats summary),
+profiles/<tag>_pmc_traffic.json (per kernel: launches, FETCH_SIZE/WRITE_SIZE averages and the HBM bytes per launch
+with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request on wide coalesced
+reads -> x2; counters are in KiB) and profiles/<tag>_summary.md.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def short(name):
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0]
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    os.makedirs("profiles", exist_ok=True)
+    ks = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(ks, f"profiles/{tag}_kernel_stats.csv")
+    stats = list(csv.DictReader(open(ks)))
+
+    def pmc(d):
+        f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f)):
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+        return agg
+
+    fe, wr = pmc(fetch_dir), pmc(write_dir)
+    traffic = {}
+    for k in fe:
+        if k in wr and fe[k][1] and wr[k][1]:
+            f_kib, w_kib = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
+            traffic[k] = {"launches_profiled": fe[k][1], "FETCH_SIZE_KiB_avg": round(f_kib, 1),
+                          "WRITE_SIZE_KiB_avg": round(w_kib, 1),
+                          "hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024)}
+    json.dump(traffic, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    with open(f"profiles/{tag}_summary.md", "w") as o:
+        o.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`\n\n")
+        o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in stats[:14]:
+            o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
+                    f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
+        o.write("\nPMC (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, KiB, per launch average; "
+                "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the x2 being the gfx950 FETCH_SIZE correction):\n\n")
+        o.write("| kernel | FETCH KiB | WRITE KiB | HBM MB / launch |\n|---|---|---|---|\n")
+        for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:10]:
+            o.write(f"| `{k}` | {v['FETCH_SIZE_KiB_avg']} | {v['WRITE_SIZE_KiB_avg']} | {v['hbm_bytes_per_launch'] / 1e6:.1f} |\n")
+    print(open(f"profiles/{tag}_summary.md").read())
+
+
+if __name__ == "__main__":
+    main()
