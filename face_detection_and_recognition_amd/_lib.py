@@ -61,6 +61,7 @@ SIGNATURES = {
     "fp_timer_destroy": (None, [_P]),
     "fp_plan_run_timed": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P, _P, C.POINTER(C.c_ubyte)]),
     "fp_timer_accumulate": (_I, [_P, C.POINTER(_F), _I]),
+    "fp_op_kernel_name": (C.c_char_p, [C.POINTER(FpOp)]),
     "fp_resize_normalize": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
     "fp_dets_to_crops": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I,
                                 _P, _P, _P, _P]),

@@ -1,5 +1,6 @@
 // capi.cpp — plan validation + executor and the small ABI utilities of libfacepath.so.
 // Compiled by hipcc as host code; kernels live in the .hip files.
+#include <stdio.h>
 #include <string.h>
 
 #include "common.h"
@@ -104,6 +105,32 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
       return FP_OK;
     default:
       return FP_ERR_UNSUPPORTED;
+  }
+}
+
+// Name of the HIP kernel an op launches (the family rocprofv3's kernel trace shows), for measurement tools.
+const char* fp_op_kernel_name(const fp_op* op) {
+  static thread_local char buf[64];
+  if (!op) return "?";
+  switch (op->kind) {
+    case FP_OP_CONV: {
+      int nb, vec, pwd;
+      fp_conv_variant(*op, &nb, &vec, &pwd);
+      snprintf(buf, sizeof(buf), "conv_igemm_kernel<%d, %s, %s>", nb, vec ? "true" : "false", pwd ? "true" : "false");
+      return buf;
+    }
+    case FP_OP_DWCONV:
+      if (op->KH == 3 && (op->stride == 1 || op->stride == 2)) snprintf(buf, sizeof(buf), "dwconv3_row_kernel<%d>", op->stride);
+      else snprintf(buf, sizeof(buf), "dwconv_kernel<%d>", op->KH);
+      return buf;
+    case FP_OP_MAXPOOL: return "maxpool_kernel";
+    case FP_OP_UPSAMPLE2X: return "upsample2x_kernel";
+    case FP_OP_COPY: return "copy_kernel";
+    case FP_OP_L2NORM: return "l2norm_kernel";
+    case FP_OP_BLAZEBLOCK:
+      snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
+      return buf;
+    default: return "?";
   }
 }
 

@@ -363,28 +363,14 @@ class CompiledPlan:
         self.lib.fp_timer_destroy(timer)
 
     def kernel_name(self, i):
-        """The HIP kernel family an op launches (matches the rocprofv3 kernel-trace names)."""
-        op = self.ops[i]
-        return op_kernel_name(op)
+        """The HIP kernel family op i launches (matches the rocprofv3 kernel-trace names)."""
+        return self.lib.fp_op_kernel_name(C.byref(self.ops[i])).decode()
 
     def algorithmic_bytes(self, i):
         """Op-granular fp32 activation bytes of op i: a conv / linear reads its input once and
         writes its output once (logical channel counts); epilogue-class ops (bias, BN, activation, residual,
         pad, concat, pool, shuffle, upsample, l2norm) are free; a fused op counts the convs it contains."""
         return self.alg_bytes[i]
-
-
-def op_kernel_name(op):
-    if op.kind == L.OP_CONV:
-        npad = round_up(op.Cout, 32) // 32
-        nb = 4 if npad % 4 == 0 else 3 if npad % 3 == 0 else 2 if npad % 2 == 0 else 1 if npad == 1 else 4
-        vec = op.Cin % 4 == 0 and op.in_ld % 4 == 0 and op.in_off % 4 == 0 and op.in_ns % 4 == 0
-        return f"conv_igemm_kernel<{nb}, {'true' if vec else 'false'}>"
-    if op.kind == L.OP_DWCONV and op.KH == 3 and op.stride in (1, 2):
-        return f"dwconv3_row_kernel<{op.stride}>"
-    return {L.OP_DWCONV: f"dwconv_kernel<{op.KH}>", L.OP_MAXPOOL: "maxpool_kernel",
-            L.OP_UPSAMPLE2X: "upsample2x_kernel", L.OP_COPY: "copy_kernel", L.OP_L2NORM: "l2norm_kernel",
-            L.OP_BLAZEBLOCK: "blazeblock_kernel"}.get(op.kind, "?")
 
 
 def validate_on_host(builder):

@@ -126,6 +126,8 @@ int fp_plan_run_timed(const fp_op* ops /*host*/, int n_ops,
                       float* arena, size_t arena_floats,
                       void* stream, void* timer, const unsigned char* op_mask /*host, n_ops*/);
 int fp_timer_accumulate(void* timer, float* ms_accum /*host, n_ops*/, int n_ops);
+/* Name of the HIP kernel family an op launches (as rocprofv3's kernel trace shows it); thread-local buffer. */
+const char* fp_op_kernel_name(const fp_op* op /*host*/);
 
 /* ------------------------------------------------------------------------- */
 /* 2. Image front end                                                          */
