@@ -53,7 +53,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // per-tap bounds checks.  Measured motivation: the generic path issued ~1900 VALU instructions per wave for
 // 128 MFMAs on the K=64 -> N=128 Mobile-FaceNet conv (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA).
 template <int NB, bool VEC, bool PWD>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr int BN = NB * 32;
   // one LDS array: A tile, then B tile; the vector epilogue reuses it as the output staging tile
   __shared__ __attribute__((aligned(16))) float smem[BM * LDA + (KC / 4) * BN * 4];
