@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 B_FRAMES = 256
 N_REF = 10000
 EMB_CAP_ROWS = 4096        # all_gather buffer rows per rank (>= faces per step per rank)
+FRAME_BYTES = 576 * 1024 * 3
 
 
 def host_cores():
@@ -130,13 +131,30 @@ def main():
         nf = step()
     torch.cuda.synchronize()
 
-    # ---- per-op timers for the roofline figures: one event set per timed step and plan ----
+    # ---- per-op timers for the roofline figures ----
+    # HIP events around an op cost a little, so: one un-timed probe step with events on every op finds the
+    # dominant kernel family; the timed steps then carry events only on that family's launches.
     det_plan = det.net.plan_for(B_FRAMES)
     n_pad = (nf + pipe.bucket - 1) // pipe.bucket * pipe.bucket
     emb_plan = emb.plan_for(n_pad)
     plans = {"blazeface": det_plan, "mobilefacenet": emb_plan}
+    probe = {k: p.new_timer() for k, p in plans.items()}
+    for name, p in plans.items():
+        p._timing = (probe[name], bytes([1] * p.n_ops))
+    step()
+    torch.cuda.synchronize()
+    fam_ms = {}
+    for name, p in plans.items():
+        p._timing = None
+        ms0 = (ctypes.c_float * p.n_ops)()
+        p.accumulate(probe[name], ms0)
+        p.destroy_timer(probe[name])
+        for i in range(p.n_ops):
+            fam_ms[p.kernel_name(i)] = fam_ms.get(p.kernel_name(i), 0.0) + ms0[i]
+    dom = max(fam_ms, key=fam_ms.get)
+    probe_share = fam_ms[dom] / sum(fam_ms.values())
     timers = {k: [p.new_timer() for _ in range(args.steps)] for k, p in plans.items()}
-    masks = {k: bytes([1] * p.n_ops) for k, p in plans.items()}
+    masks = {k: bytes([1 if p.kernel_name(i) == dom else 0 for i in range(p.n_ops)]) for k, p in plans.items()}
 
     if world > 1:
         dist.barrier()
@@ -168,25 +186,37 @@ def main():
     # ---- roofline of the dominant kernel (rank 0) ----
     roof = None
     if rank == 0:
-        per_kernel = {}
+        ms_tot, launches, bytes_tot = 0.0, 0, 0
         for name, p in plans.items():
             ms = (ctypes.c_float * p.n_ops)()
             for t in timers[name]:
                 p.accumulate(t, ms)
                 p.destroy_timer(t)
             for i in range(p.n_ops):
-                kn = p.kernel_name(i)
-                e = per_kernel.setdefault(kn, [0.0, 0, 0])
-                e[0] += ms[i]
-                e[1] += args.steps
-                e[2] += p.algorithmic_bytes(i) * args.steps
-        dom, (ms_tot, launches, bytes_tot) = max(per_kernel.items(), key=lambda kv: kv[1][0])
+                if masks[name][i]:
+                    ms_tot += ms[i]
+                    launches += args.steps
+                    bytes_tot += p.algorithmic_bytes(i) * args.steps
         achieved = bytes_tot / (ms_tot * 1e-3) / 1e9 if ms_tot > 0 else 0.0
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/*_pmc_traffic.json,
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH x2 correction), if present
+        traffic = None
+        try:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+            traffic = json.load(open(latest)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+        # whole-pipeline view: op-granular bytes of both networks + letterbox per step over the step time
+        pipe_bytes = sum(p.algorithmic_bytes(i) for p in plans.values() for i in range(p.n_ops)) + \
+            B_FRAMES * (FRAME_BYTES + 256 * 256 * 3 * 4)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "pipeline_algorithmic_GBps": round(pipe_bytes / (elapsed / args.steps) / 1e9, 1),
+                "pipeline_frac": round(pipe_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "avg_launch_us": round(ms_tot * 1e3 / launches, 2), "launches_per_step": launches // args.steps,
                 "algorithmic_bytes_per_launch": int(bytes_tot // launches),
-                "share_of_timed_kernel_ms": round(ms_tot / sum(v[0] for v in per_kernel.values()), 3)}
+                "share_of_network_kernel_time": round(probe_share, 3)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

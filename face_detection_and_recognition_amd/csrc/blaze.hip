@@ -37,6 +37,7 @@ struct BlazeArgs {
 };
 
 constexpr int TM = 128;
+constexpr size_t FP_BLAZEBLOCK_MAX_LDS = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 
 template <int NB>
 __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
@@ -73,50 +74,86 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
                                               : *(const f32x4*)(p.bd + ((long)i * 4 - 9 * p.Cin));
   __syncthreads();
 
-  // phase 1: depthwise + shortcut.  Branch-free taps: all 9 loads of an item are issued back to back
-  // (addresses clamped into the map, out-of-range taps masked to zero afterwards).
+  // phase 1: depthwise + shortcut.  One lane = 4 consecutive output pixels (same image row: OW % 4 == 0) x 4
+  // channels: the 3 x (3*s+3) input window is loaded once per row with branch-free, clamped 16-B loads and slides
+  // over the 4 outputs (18 loads per 4 outputs at s=1 instead of 36; 27 instead of 36 at s=2).
   const int KC4 = p.Kpad >> 2;  // A columns (in float4) incl. zero padding
-  for (int it = tid; it < TM * KC4; it += 256) {
-    const int r = it / KC4, c4 = it - r * KC4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = tid; it < (TM / 4) * KC4; it += 256) {
+    const int g = it / KC4, c4 = it - g * KC4;
+    const int r = g * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {z, z, z, z}, sc[4] = {z, z, z, z};
     if (c4 < p.C4) {
       long m = m0 + r;
-      m = m < p.M ? m : p.M - 1;  // tail rows recompute the last pixel; they are never stored
+      m = m < p.M ? m : p.M - 4;  // tail groups recompute the last pixels; they are never stored
       const unsigned mm = (unsigned)m;
       const unsigned img = mm / (unsigned)p.OHW;
       const unsigned rem = mm - img * (unsigned)p.OHW;
       const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
       const int c = c4 * 4;
       const float* ib = p.in + (long)img * p.in_ns + c;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      f32x4 xv[9];
-      const int iy0 = p.stride == 1 ? oy - 1 : 2 * oy, ix0 = p.stride == 1 ? ox - 1 : 2 * ox;
+      const f32x4 bias = *(const f32x4*)&Ws[9 * p.Cin + c];
+      if (p.stride == 1) {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = iy0 + ky;
-        const bool vy = (unsigned)iy < (unsigned)p.H;
-        const float* rowp = ib + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = oy - 1 + ky;
+          const bool vy = (unsigned)iy < (unsigned)p.H;
+          const float* rowp = ib + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+          f32x4 x[6];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = ix0 + kx;
-          const bool v = vy && ((unsigned)ix < (unsigned)p.W);
-          const f32x4 x = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
-          xv[ky * 3 + kx] = v ? x : z;
+          for (int j = 0; j < 6; ++j) {
+            const int ix = ox - 1 + j;
+            const bool v = vy && ((unsigned)ix < (unsigned)p.W);
+            const f32x4 t = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
+            x[j] = v ? t : z;
+          }
+          const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * p.Cin + c];
+          const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * p.Cin + c];
+          const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * p.Cin + c];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[q] += x[q] * w0 + x[q + 1] * w1 + x[q + 2] * w2;
+            if (ky == 1) sc[q] = x[q + 1];  // centre tap = x itself
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = 2 * oy + ky;
+          const bool vy = iy < p.H;
+          const float* rowp = ib + (long)min(iy, p.H - 1) * p.W * p.in_ld;
+          f32x4 x[9];
+#pragma unroll
+          for (int j = 0; j < 9; ++j) {
+            const int ix = 2 * ox + j;
+            const bool v = vy && ix < p.W;
+            const f32x4 t = *(const f32x4*)(rowp + (long)min(ix, p.W - 1) * p.in_ld);
+            x[j] = v ? t : z;
+          }
+          const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * p.Cin + c];
+          const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * p.Cin + c];
+          const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * p.Cin + c];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[q] += x[2 * q] * w0 + x[2 * q + 1] * w1 + x[2 * q + 2] * w2;
+            if (ky < 2) {  // rows 0,1 x cols 2q,2q+1 are the 2x2 max-pool window (always inside the map)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float mx = fmaxf(x[2 * q][e], x[2 * q + 1][e]);
+                sc[q][e] = ky == 0 ? mx : fmaxf(sc[q][e], mx);
+              }
+            }
+          }
         }
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc += xv[t] * *(const f32x4*)&Ws[t * p.Cin + c];
-      acc += *(const f32x4*)&Ws[9 * p.Cin + c];
-      if (p.stride == 1) {
-        sc = xv[4];  // centre tap = x itself
-      } else {
-        // taps (0..1, 0..1) are the 2x2 max-pool window (always inside the map: H, W even)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sc[e] = fmaxf(fmaxf(xv[0][e], xv[1][e]), fmaxf(xv[3][e], xv[4][e]));
-      }
+      for (int q = 0; q < 4; ++q) acc[q] += bias;
     }
-    *(f32x4*)&At[r * LDT + c4 * 4] = acc;
-    if (c4 < p.C4) *(f32x4*)&St[r * LDS_ + c4 * 4] = sc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *(f32x4*)&At[(r + q) * LDT + c4 * 4] = acc[q];
+      if (c4 < p.C4) *(f32x4*)&St[(r + q) * LDS_ + c4 * 4] = sc[q];
+    }
   }
   __syncthreads();
 
@@ -184,9 +221,9 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
   if (op.out_cmul != 1 || op.out_ld != op.Cout || op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return FP_ERR_UNSUPPORTED;
   if (op.stride == 1 && (op.OH != op.H || op.OW != op.W)) return FP_ERR_INVALID_ARG;
   if (op.stride == 2 && (op.H % 2 || op.W % 2 || op.OH != op.H / 2 || op.OW != op.W / 2)) return FP_ERR_INVALID_ARG;
-  if (op.Cout > 128 || op.res_C > op.Cin) return FP_ERR_UNSUPPORTED;
+  if (op.Cout > 128 || op.res_C > op.Cin || op.OW % 4) return FP_ERR_UNSUPPORTED;
   const size_t lds = fp_blazeblock_lds_bytes(op.Cin, op.Cout);
-  if (lds > 64 * 1024) return FP_ERR_UNSUPPORTED;  // the planner emits the unfused pair for wider blocks
+  if (lds > FP_BLAZEBLOCK_MAX_LDS) return FP_ERR_UNSUPPORTED;  // the planner emits the unfused pair for wider blocks
   BlazeArgs a;
   a.in = arena + op.in_off;
   a.out = arena + op.out_off;
@@ -205,13 +242,21 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;
   a.ntiles = fp_ceil_div(a.M, TM);
   dim3 grid((unsigned)a.ntiles), block(256);
+#define FP_BB_CASE(NBV)                                                                                     \
+  case NBV:                                                                                                 \
+    if (lds > 64 * 1024)  /* opt in to more than the default 64 KiB of dynamic LDS (idempotent) */          \
+      (void)hipFuncSetAttribute((const void*)blazeblock_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                  \
+    hipLaunchKernelGGL((blazeblock_kernel<NBV>), grid, block, lds, s, a);                                   \
+    break;
   switch (a.Npad / 32) {
-    case 1: hipLaunchKernelGGL((blazeblock_kernel<1>), grid, block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL((blazeblock_kernel<2>), grid, block, lds, s, a); break;
-    case 3: hipLaunchKernelGGL((blazeblock_kernel<3>), grid, block, lds, s, a); break;
-    case 4: hipLaunchKernelGGL((blazeblock_kernel<4>), grid, block, lds, s, a); break;
+    FP_BB_CASE(1)
+    FP_BB_CASE(2)
+    FP_BB_CASE(3)
+    FP_BB_CASE(4)
     default: return FP_ERR_UNSUPPORTED;
   }
+#undef FP_BB_CASE
   FP_CHECK_LAUNCH();
   return FP_OK;
 }

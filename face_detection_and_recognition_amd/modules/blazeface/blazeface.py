@@ -40,8 +40,8 @@ class BlazeBlock(_NoCompute):
         else:
             OH, OW, pad = x.H, x.W, (1, 1)
             res_mode = L.RES_ADD_BEFORE_ACT
-        if (BlazeBlock.FUSE and self.kernel_size == 3 and x.coff == 0 and
-                pb.blazeblock_lds_bytes(x.C, cpad(self.out_channels)) <= 64 * 1024):
+        if (BlazeBlock.FUSE and self.kernel_size == 3 and x.coff == 0 and OW % 4 == 0 and
+                pb.blazeblock_lds_bytes(x.C, cpad(self.out_channels)) <= 80 * 1024):
             y = pb.new_buf(OH, OW, self.out_channels)
             pb.blazeblock(x, npy(dw.weight), npy(dw.bias), npy(pw.weight), npy(pw.bias), y.view(), self.stride)
             return y
