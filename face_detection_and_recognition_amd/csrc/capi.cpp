@@ -40,7 +40,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const bool spatial = op.kind != FP_OP_L2NORM && op.kind != FP_OP_COPY;
   const int OH = spatial ? op.OH : op.H, OW = spatial ? op.OW : op.W;
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
-  const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK) ? op.Cout : op.Cin;
+  const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW) ? op.Cout : op.Cin;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // input extent
   const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
@@ -50,7 +50,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (!span_ok(op.out_off, out_ext, arena_floats)) return FP_ERR_BOUNDS;
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
-  if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK) {
+  if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
+      op.kind == FP_OP_DWPW) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -75,6 +76,13 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.kind == FP_OP_DWCONV) {
     if (!span_ok(op.w_off, (int64_t)op.KH * op.KW * op.Cin, weight_floats)) return FP_ERR_BOUNDS;
   }
+  if (op.kind == FP_OP_DWPW) {
+    // w_off: [9*G taps][G scale][G bias][G slope]; slope_off: [Kpad*Npad packed 1x1][Cout4 scale][Cout4 bias]
+    if (!span_ok(op.w_off, 12 * (int64_t)op.Cin, weight_floats)) return FP_ERR_BOUNDS;
+    const int64_t pw = ((op.Cin + 7) / 8 * 8) * (int64_t)((op.Cout + 31) / 32 * 32) + 2 * (int64_t)((op.Cout + 3) / 4 * 4);
+    if (!span_ok(op.slope_off, pw, weight_floats)) return FP_ERR_BOUNDS;
+    if (op.act != FP_ACT_NONE && op.act != FP_ACT_PRELU) return FP_ERR_INVALID_ARG;
+  }
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV) {
     if (op.scale_off >= 0 && !span_ok(op.scale_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
     if (op.bias_off >= 0 && !span_ok(op.bias_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
@@ -82,7 +90,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.act == FP_ACT_PRELU && op.slope_off < 0) return FP_ERR_INVALID_ARG;
     if (op.act < FP_ACT_NONE || op.act > FP_ACT_SILU) return FP_ERR_INVALID_ARG;
   }
-  if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK) && op.res_mode != FP_RES_NONE) {
+  if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW) && op.res_mode != FP_RES_NONE) {
     if (op.res_mode < FP_RES_NONE || op.res_mode > FP_RES_POOL2_BEFORE_ACT) return FP_ERR_INVALID_ARG;
     if (op.res_C <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
     int rh = OH, rw = OW;
@@ -102,6 +110,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_COPY:
     case FP_OP_L2NORM:
     case FP_OP_BLAZEBLOCK:
+    case FP_OP_DWPW:
       return FP_OK;
     default:
       return FP_ERR_UNSUPPORTED;
@@ -130,6 +139,10 @@ const char* fp_op_kernel_name(const fp_op* op) {
     case FP_OP_BLAZEBLOCK:
       snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
+    case FP_OP_DWPW:
+      snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
+               (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
+      return buf;
     default: return "?";
   }
 }
@@ -152,6 +165,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, hipStr
     case FP_OP_COPY: return fp_launch_copy(op, arena, s);
     case FP_OP_L2NORM: return fp_launch_l2norm(op, arena, s);
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
+    case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
     default: return FP_ERR_UNSUPPORTED;
   }
 }

@@ -32,4 +32,5 @@ int fp_launch_upsample2x(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd);  // conv_igemm template arguments for an op

@@ -83,8 +83,22 @@ class Depth_Wise(_NoCompute):
         self.project = Linear_block(groups, out_c, kernel=(1, 1), padding=(0, 0), stride=(1, 1))
         self.residual = residual
 
+    FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
+
     def emit(self, pb, x):
         a = self.conv.emit(pb, x)
+        dw, pj = self.conv_dw, self.project
+        if (Depth_Wise.FUSE and dw.k == 3 and dw.p == 1 and dw.groups % 64 == 0 and pj.out_c % 4 == 0 and
+                pj.out_c <= 128):
+            OH = (a.H + 2 - 3) // dw.s + 1
+            OW = (a.W + 2 - 3) // dw.s + 1
+            y = pb.new_buf(OH, OW, pj.out_c)
+            ds, db = _affine(dw.bn)
+            ps, pbias = _affine(pj.bn)
+            pb.dwpw(a.view(), npy(dw.conv.weight), ds, db, npy(dw.prelu.weight), npy(pj.conv.weight), ps, pbias,
+                    y.view(), dw.s, res=x if self.residual else None)
+            pb.free(a)
+            return y
         b = self.conv_dw.emit(pb, a.view())
         pb.free(a)
         y = self.project.emit(pb, b.view(), res=x if self.residual else None)

@@ -272,6 +272,36 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * cin + opix * cin + opix * cin + opix * cout))
         return out
 
+    def dwpw(self, x, dw_w, dw_scale, dw_bias, dw_slope, pw_w, pw_scale, pw_bias, out, stride, res=None):
+        """Fused Depth_Wise tail (mobile_facenet.py:72-85): dw3x3 stride s (+BN affine, +PReLU) -> 1x1 (+BN affine)
+        [+ res].  x has G (multiple of 64) channels."""
+        G = dw_w.shape[0]
+        cout, cin = pw_w.shape[0], pw_w.shape[1]
+        assert cin == G == x.C and G % 64 == 0 and out.cmul == 1 and out.coff == 0 and out.buf.ld == out.C
+        op = self._base(L.OP_DWPW, x, out, out.H, out.W)
+        op.Cout = out.C
+        op.KH = op.KW = 3
+        op.stride = stride
+        op.pad_t = op.pad_l = 1
+        op.act = L.ACT_PRELU if dw_slope is not None else L.ACT_NONE
+        slope = dw_slope if dw_slope is not None else np.zeros(G, np.float32)
+        op.w_off = self.add_weight(np.concatenate([pack_dw_weight(dw_w, G), pad_vec(dw_scale, G), pad_vec(dw_bias, G),
+                                                   pad_vec(slope, G)]))
+        c4 = round_up(out.C, 4)
+        op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(pw_w, G, out.C), pad_vec(pw_scale, c4),
+                                                       pad_vec(pw_bias, c4)]))
+        if res is not None:
+            assert res.cmul == 1
+            op.res_mode = L.RES_ADD_AFTER_ACT
+            op.res_ld, op.res_ns = res.buf.ld, res.buf.ns
+            op.res_off = res.buf.off + res.coff
+            op.res_C = min(res.C, out.C)
+            op.res_H, op.res_W = res.H, res.W
+        self.ops.append(op)
+        opix = out.H * out.W
+        self.alg_bytes.append(4 * self.N * (x.H * x.W * G + opix * G + opix * G + opix * cout))
+        return out
+
     def maxpool(self, x, out, k, stride, pad):
         assert out.C == x.C
         op = self._base(L.OP_MAXPOOL, x, out, out.H, out.W)

@@ -55,7 +55,8 @@ enum fp_op_kind {
   FP_OP_UPSAMPLE2X = 4, /* nearest-neighbour 2x */
   FP_OP_COPY = 5,       /* channel-slice copy (concat / chunk / shuffle interleave) */
   FP_OP_L2NORM = 6,     /* out[m,:] = in[m,:] / ||in[m,:]||_2 over Cin channels (mobile_facenet.py:30-33) */
-  FP_OP_BLAZEBLOCK = 7  /* fused BlazeBlock: dw3x3 -> 1x1 -> (+shortcut) -> ReLU (blazeface.py:12-47) */
+  FP_OP_BLAZEBLOCK = 7, /* fused BlazeBlock: dw3x3 -> 1x1 -> (+shortcut) -> ReLU (blazeface.py:12-47) */
+  FP_OP_DWPW = 8        /* fused Depth_Wise tail: dw3x3(+BN,+PReLU) -> 1x1(+BN) [+x] (mobile_facenet.py:72-85) */
 };
 
 enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
@@ -102,6 +103,10 @@ typedef struct fp_op {
  *            Npad = roundup(Cout, 32); element (k, n) at ((k/4)*Npad + n)*4 + k%4; zero padded.
  *   DWCONV : Wd[KH*KW][C]
  *   scale / bias / slope : [Cout]
+ *   DWPW   : w_off     -> [9][G] depthwise taps, [G] scale, [G] bias, [G] PReLU slope   (12*G floats)
+ *            slope_off -> packed 1x1 weights as for CONV (K = G), then [roundup(Cout,4)] scale, [roundup(Cout,4)] bias
+ *            act = FP_ACT_PRELU if the depthwise has a PReLU; res_mode = FP_RES_ADD_AFTER_ACT adds res after the 1x1.
+ *   BLAZEBLOCK : w_off -> [9][Cin] taps, scale_off -> [Cin] depthwise bias, slope_off -> packed 1x1, bias_off -> [Cout]
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -199,6 +199,41 @@ def test_mobilefacenet_depthwise_vs_reference_golden(dev):
     assert rel_err(yb, g["y_down"]) < 1e-5
 
 
+def test_mobilefacenet_fused_and_unfused_plans_agree(dev):
+    """FP_OP_DWPW (csrc/dwpw.hip: conv_dw + project fused) against the DWCONV + CONV pair and the golden,
+    plus block-level checks at every map size of the network (28: P=4, 14: P=2, 7: P=1; stride 1 and 2)."""
+    g = golden("mobilefacenet_forward")
+    outs = {}
+    for fuse in (True, False):
+        Depth_Wise.FUSE = fuse
+        try:
+            net = MobileFaceNet(512)
+            net.load_state_dict(synth_state_dict(net.state_dict(), int(g["seed"])))
+            net = net.to(dev)
+            plan = net.plan_for(4)
+            kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
+            assert (L.OP_DWPW in kinds) == fuse
+            outs[fuse] = net(torch.from_numpy(g["x"])).cpu().numpy().copy()
+        finally:
+            Depth_Wise.FUSE = True
+    assert np.abs(outs[True] - g["emb"]).max() < 1e-4 and np.abs(outs[False] - g["emb"]).max() < 1e-4
+    assert np.abs(outs[True] - outs[False]).max() < 2e-6
+    rng = np.random.default_rng(21)
+    for cin, cout, groups, stride, hw, residual in ((64, 64, 128, 1, 28, True), (64, 128, 256, 2, 28, False),
+                                                    (128, 128, 256, 1, 14, True), (128, 128, 512, 2, 14, False),
+                                                    (128, 128, 256, 1, 7, True), (64, 64, 128, 2, 56, False)):
+        blk = Depth_Wise(cin, cout, residual=residual, kernel=(3, 3), stride=(stride, stride), padding=(1, 1),
+                         groups=groups)
+        sd = synth_state_dict(blk.state_dict(), 700 + groups + stride + hw)
+        blk.load_state_dict(sd)
+        x = rng.normal(0, 1, (3, cin, hw, hw)).astype(np.float32)
+        y = run_block(blk, x, dev, None, cout)
+        ref = mobilefacenet_ref._depth_wise({k: torch.as_tensor(v) for k, v in sd.items()}, "", torch.from_numpy(x),
+                                            stride, residual).numpy()
+        assert y.shape == ref.shape
+        assert rel_err(y, ref) < 1e-5, (cin, cout, groups, stride, hw)
+
+
 def test_mobilefacenet_forward_vs_reference_golden(dev):
     g = golden("mobilefacenet_forward")
     net = MobileFaceNet(512)
