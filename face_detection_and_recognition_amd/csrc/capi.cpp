@@ -134,7 +134,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       return buf;
     case FP_OP_MAXPOOL: return "maxpool_kernel";
     case FP_OP_UPSAMPLE2X: return "upsample2x_kernel";
-    case FP_OP_COPY: return "copy_kernel";
+    case FP_OP_COPY:
+      return (op->out_cmul == 1 && op->Cin % 4 == 0 && op->in_ld % 4 == 0 && op->out_ld % 4 == 0 && op->in_off % 4 == 0 &&
+              op->out_off % 4 == 0 && op->in_ns % 4 == 0 && op->out_ns % 4 == 0) ? "copy4_kernel" : "copy_kernel";
     case FP_OP_L2NORM: return "l2norm_kernel";
     case FP_OP_BLAZEBLOCK:
       snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);

@@ -538,6 +538,19 @@ __global__ __launch_bounds__(256) void copy_kernel(CopyArgs p) {
       p.in[(long)img * p.in_ns + (long)pix * p.in_ld + c];
 }
 
+// Same copy with 16-byte accesses (dense channel slices: torch.cat, common.py:241-242).
+__global__ __launch_bounds__(256) void copy4_kernel(CopyArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int C4 = p.C >> 2;
+  const int c4 = (int)(idx % C4);
+  const long m = idx / C4;
+  const int img = (int)(m / p.HW);
+  const int pix = (int)(m - (long)img * p.HW);
+  *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c4 * 4) =
+      *(const f32x4*)(p.in + (long)img * p.in_ns + (long)pix * p.in_ld + c4 * 4);
+}
+
 // l2_norm (mobile_facenet.py:30-33): one wave per row, x / sqrt(sum x^2), no epsilon.
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* in, float* out, long M, int D, long in_ld, long out_ld) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -705,6 +718,14 @@ int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s) {
   a.out = arena + op.out_off;
   a.C = op.Cin; a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.out_cmul = op.out_cmul;
   a.HW = op.H * op.W; a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  const bool v4 = op.out_cmul == 1 && op.Cin % 4 == 0 && op.in_ld % 4 == 0 && op.out_ld % 4 == 0 && op.in_off % 4 == 0 &&
+                  op.out_off % 4 == 0 && op.in_ns % 4 == 0 && op.out_ns % 4 == 0;
+  if (v4) {
+    a.total = (long)op.N * a.HW * (a.C / 4);
+    hipLaunchKernelGGL(copy4_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
+    FP_CHECK_LAUNCH();
+    return FP_OK;
+  }
   a.total = (long)op.N * a.HW * a.C;
   hipLaunchKernelGGL(copy_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
   FP_CHECK_LAUNCH();

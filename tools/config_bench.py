@@ -1,0 +1,89 @@
+"""Measures the other BASELINE.json configs on one GPU (they are parity-test cases, not the headline bench line):
+  [2] YOLOv5n-face 640x640 batch 256 + batched NMS
+  [3] YOLOv5s-face detect -> Mobile-FaceNet 112x112, 1024 crops
+  [4] cosine filter 1M gallery x 10k reference x 512-d (single-GPU share and the full problem)
+Seeded synthetic weights/inputs; prints one JSON line per config."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from face_detection_and_recognition_amd import similarity as S  # noqa: E402
+from face_detection_and_recognition_amd import workload as W  # noqa: E402
+from face_detection_and_recognition_amd.modules.yolov5_face import nms_face_device, preprocess_batch  # noqa: E402
+from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model  # noqa: E402
+from face_detection_and_recognition_amd.synth import synth_state_dict  # noqa: E402
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def yolo(name, dev, B=256):
+    m = Model(name)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 11))
+    m = m.fuse().to(dev)
+    with torch.no_grad():                      # few candidates per image, like a trained detector
+        for conv in m.model[-1].m:
+            conv.bias.view(3, 16)[:, 4] -= 6.0
+            conv.bias.view(3, 16)[:, 15] += 4.0
+    frames = W.make_frames(B, dev, seed=5)
+    plan = preprocess_batch(m, frames, (640, 640))
+    t_pre = timeit(lambda: preprocess_batch(m, frames, (640, 640)))
+    t_fwd = timeit(lambda: m.run_plan(plan))
+    z = m.run_plan(plan)
+    t_nms = timeit(lambda: nms_face_device(z, 0.4, 0.5))
+    out, cnt, _, over = nms_face_device(z, 0.4, 0.5)
+    alg = sum(plan.algorithmic_bytes(i) for i in range(plan.n_ops))
+    print(json.dumps({"config": f"{name}-face 640x640 batch {B} + batched NMS", "letterbox_ms": round(t_pre * 1e3, 3),
+                      "forward_decode_ms": round(t_fwd * 1e3, 3), "nms_ms": round(t_nms * 1e3, 3),
+                      "img_per_s": round(B / (t_pre + t_fwd + t_nms), 1), "dets_per_img": float(cnt.float().mean()),
+                      "overflow": int(over.sum()), "algorithmic_GBps_forward": round(alg / t_fwd / 1e9, 1),
+                      "n_ops": plan.n_ops}), flush=True)
+    return m
+
+
+def embed_1024(dev):
+    emb = W.build_embedder(dev)
+    plan = emb.plan_for(1024)
+    plan.input.normal_()
+    t = timeit(lambda: plan.run())
+    alg = sum(plan.algorithmic_bytes(i) for i in range(plan.n_ops))
+    print(json.dumps({"config": "Mobile-FaceNet 112x112 batch 1024 crops", "ms": round(t * 1e3, 3),
+                      "crops_per_s": round(1024 / t, 1), "algorithmic_GBps": round(alg / t / 1e9, 1)}), flush=True)
+
+
+def cosine(dev, M, Nr=10000, D=512):
+    g = torch.Generator(device=dev).manual_seed(42)
+    G = torch.randn((M, D), device=dev, generator=g)
+    R = torch.randn((Nr, D), device=dev, generator=g)
+    ginv, rinv = S.row_inv_norm(G), S.row_inv_norm(R)
+    t = timeit(lambda: S.cosine_filter(G, R, 0.3, ginv, rinv), n=3, warm=1)
+    print(json.dumps({"config": f"cosine filter {M} x {Nr} x {D}", "ms": round(t * 1e3, 2),
+                      "TFLOPs": round(2.0 * M * Nr * D / t / 1e12, 1), "pair_scores_per_s": round(M * Nr / t, 0)}),
+          flush=True)
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    which = sys.argv[1:] or ["yolov5n", "yolov5s", "embed", "cosine"]
+    if "yolov5n" in which:
+        yolo("yolov5n", dev)
+    if "yolov5s" in which:
+        yolo("yolov5s", dev)
+    if "embed" in which:
+        embed_1024(dev)
+    if "cosine" in which:
+        cosine(dev, 125_000)
+        cosine(dev, 1_000_000)
