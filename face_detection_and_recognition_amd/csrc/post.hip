@@ -325,7 +325,11 @@ __global__ __launch_bounds__(256) void yolo_nms_kernel(const float* __restrict__
     }
     __syncthreads();
     const int cursor = cursor_s;
-    if (cursor >= n || nout >= max_out) break;
+    if (cursor >= n) break;
+    if (nout >= max_out) {  // more survivors than the output holds: report it, the host raises
+      if (tid == 0) overflow[b] = 1;
+      break;
+    }
     const int i = order[cursor];
     const float4 bi = sbox[i];
     if (tid < OUTC) {

@@ -10,7 +10,7 @@ import torch
 from ... import _lib as L
 from ..utils.image import scale_coords
 
-MAX_CAND = 4096      # per-image candidate capacity of the NMS kernel; more raises (the reference has no cap)
+MAX_DET = 2048       # kept boxes per image of the fast path; beyond it the call is repeated without a cap
 
 
 def _nms_common(fn_name, prediction, conf_thres, iou_thres, max_det, out_cols):
@@ -23,15 +23,16 @@ def _nms_common(fn_name, prediction, conf_thres, iou_thres, max_det, out_cols):
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     keep = torch.empty((B, max_det), dtype=torch.int32, device=dev)
     over = torch.empty((B,), dtype=torch.int32, device=dev)
-    nbytes = lib.fp_yolo_nms_scratch_bytes(B, MAX_CAND)
+    max_cand = (n_rows + 3) // 4 * 4          # every row may be a candidate, as in the reference
+    nbytes = lib.fp_yolo_nms_scratch_bytes(B, max_cand)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     fn = getattr(lib, fn_name)
-    L.check(fn(L.ptr(pred), B, n_rows, float(conf_thres), float(iou_thres), MAX_CAND, max_det, L.ptr(out), L.ptr(cnt),
+    L.check(fn(L.ptr(pred), B, n_rows, float(conf_thres), float(iou_thres), max_cand, max_det, L.ptr(out), L.ptr(cnt),
                L.ptr(keep), L.ptr(over), L.ptr(scratch), nbytes, L.current_stream(dev)), fn_name)
     return out, cnt, keep, over
 
 
-def nms_face_device(prediction, conf_thres=0.25, iou_thres=0.45, max_det=1024):
+def nms_face_device(prediction, conf_thres=0.25, iou_thres=0.45, max_det=MAX_DET):
     """Device-resident form: (out [B, max_det, 16], counts [B], keep_idx [B, max_det], overflow [B])."""
     return _nms_common("fp_yolo_nms", prediction, conf_thres, iou_thres, max_det, 16)
 
@@ -42,9 +43,9 @@ def non_max_suppression_face(prediction, conf_thres=0.25, iou_thres=0.45, classe
     if classes is not None or labels:
         raise NotImplementedError("class filtering / autolabelling are not part of the face path (nc = 1)")
     out, cnt, _, over = nms_face_device(prediction, conf_thres, iou_thres)
-    cnt, over = cnt.cpu().tolist(), over.cpu().tolist()
-    if any(over):
-        raise L.FacepathError(f"an image had more than {MAX_CAND} NMS candidates")
+    if int(over.sum()):      # more than MAX_DET survivors in some image (untrained weights): exact re-run, no cap
+        out, cnt, _, over = nms_face_device(prediction, conf_thres, iou_thres, max_det=prediction.shape[1])
+    cnt = cnt.cpu().tolist()
     return [out[i, :k].clone() if k > 0 else torch.zeros((0, 16), device=prediction.device)
             for i, k in enumerate(cnt)]
 
@@ -52,10 +53,10 @@ def non_max_suppression_face(prediction, conf_thres=0.25, iou_thres=0.45, classe
 def w_non_max_suppression(prediction, num_classes=1, conf_thres=0.5, nms_thres=0.4):
     """onnx_utils.py:107-163 for num_classes = 1: list of (k, 7) tensors or None per image."""
     assert num_classes == 1
-    out, cnt, _, over = _nms_common("fp_yolo_w_nms", prediction, conf_thres, nms_thres, 1024, 7)
-    cnt, over = cnt.cpu().tolist(), over.cpu().tolist()
-    if any(over):
-        raise L.FacepathError(f"an image had more than {MAX_CAND} NMS candidates")
+    out, cnt, _, over = _nms_common("fp_yolo_w_nms", prediction, conf_thres, nms_thres, MAX_DET, 7)
+    if int(over.sum()):
+        out, cnt, _, over = _nms_common("fp_yolo_w_nms", prediction, conf_thres, nms_thres, prediction.shape[1], 7)
+    cnt = cnt.cpu().tolist()
     return [out[i, :k].clone() if k > 0 else None for i, k in enumerate(cnt)]
 
 

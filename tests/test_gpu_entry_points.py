@@ -1,0 +1,119 @@
+"""GPU tests of the reference-named entry points (CLI surface + plugin API) on synthetic weights / images."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from face_detection_and_recognition_amd import workload as W
+from face_detection_and_recognition_amd.modules.blazeface.blazeface import generate_anchors
+from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import MobileFaceNet
+from face_detection_and_recognition_amd.modules.utils.inference import get_dets_bboxes_confs_lmarks_areas
+from face_detection_and_recognition_amd.synth import synth_state_dict
+from oracle import blazeface_ref, image_ref, mobilefacenet_ref, similarity_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _save_png_as_jpg_free(path, arr):
+    Image.fromarray(arr[..., ::-1]).save(path, quality=95)       # arr is BGR
+
+
+def test_detect_face_blazeface_cli_matches_oracle(dev, tmp_path):
+    from face_detection_and_recognition_amd import detect_face_blazeface
+    from face_detection_and_recognition_amd.modules.utils.inference import load_image
+    frames = W.make_frames(8, dev, seed=3)
+    det = W.build_detector(dev, frames, cand_per_frame=48)
+    wpath = str(tmp_path / "blazefaceback.pth")
+    torch.save({k: v.cpu() for k, v in det.net.state_dict().items()}, wpath)
+    np.save(str(tmp_path / "anchors.npy"), generate_anchors(True))
+    ipath = str(tmp_path / "frame.jpg")
+    _save_png_as_jpg_free(ipath, frames[0].cpu().numpy())
+    post = detect_face_blazeface.main(["-i", ipath, "--md", wpath, "--mt", "back", "--dt", "0.7", "--at", "0.12",
+                                       "-d", "hip:0"])
+    # oracle on the decoded jpg (same decoder), reference flow: letterbox -> net -> decode -> wNMS -> B7
+    img = load_image(ipath)
+    sd = {k: v.cpu() for k, v in det.net.state_dict().items()}
+    lb = image_ref.pad_resize_image(img, (256, 256))[..., ::-1].copy()
+    faces, _ = blazeface_ref.predict_on_batch(sd, torch.from_numpy(lb).permute(2, 0, 1).unsqueeze(0),
+                                              torch.from_numpy(generate_anchors(True)), True)
+    d = faces[0].numpy()[:, [1, 0, 3, 2] + list(range(4, 17))]
+    ref = image_ref.dets_to_boxes(d.copy(), (img.shape[1], img.shape[0]), (256, 256), 0.7, 0.12)
+    assert len(post.boxes) == len(ref["boxes"]) > 0
+    assert np.abs(post.boxes - ref["boxes"]).max() <= 1.0          # rounded pixel coordinates
+    np.testing.assert_allclose(post.bbox_confs, ref["bbox_confs"], atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        detect_face_blazeface.main(["-i", ipath, "--md", str(tmp_path / "x.tflite"), "-d", "hip"])
+    with pytest.raises(FileNotFoundError):
+        detect_face_blazeface.main(["-i", str(tmp_path / "missing.jpg"), "--md", wpath, "-d", "hip"])
+
+
+def test_filter_faces_using_reference_cli(dev, tmp_path):
+    from face_detection_and_recognition_amd.similar_face_filtering import filter_faces_using_reference as F
+    assert F._fix_path_for_globbing("data/") == "data/*" and F._fix_path_for_globbing("data") == "data/*"
+    rng = np.random.default_rng(0)
+    net = MobileFaceNet(512)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 300))
+    wpath = str(tmp_path / "mfn.pth")
+    torch.save(net.state_dict(), wpath)
+    base = {c: rng.integers(0, 256, (64, 64, 3), dtype=np.uint8) for c in ("class_a", "class_b")}
+    for root, n in (("ref", 6), ("unf", 9)):
+        for c in base:
+            os.makedirs(tmp_path / root / c)
+            for i in range(n):
+                noise = rng.integers(-40, 40, base[c].shape) if (root == "unf" and i % 3 == 2) else \
+                    rng.integers(-4, 4, base[c].shape)
+                img = np.clip(base[c].astype(int) + noise, 0, 255).astype(np.uint8)
+                Image.fromarray(img).save(tmp_path / root / c / f"{c}_{i}.jpg", quality=95)
+    assert F.get_class_name_list(str(tmp_path / "ref")) == ["class_a", "class_b"]
+    F.main(["--ud", str(tmp_path / "unf"), "--rd", str(tmp_path / "ref"), "--td", str(tmp_path / "out"), "-m", wpath,
+            "-b", "4", "-r", "32", "-d", "hip:0"])
+    for c in base:
+        clean = os.listdir(tmp_path / "out" / "clean" / c)
+        unclean = os.listdir(tmp_path / "out" / "unclean" / c)
+        assert len(clean) + len(unclean) == 9
+    # the filter decision equals the reference arithmetic on the same embeddings (oracle network + numpy filter)
+    netd = net.to(dev)
+    paths = sorted(str(p) for p in (tmp_path / "unf" / "class_a").glob("*.jpg"))
+    refs = [str(p) for p in (tmp_path / "ref" / "class_a").glob("*.jpg")]
+    e_hip = F.embed_images(netd, paths, 4).cpu().numpy()
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+
+    def emb_ref(p):
+        img = F.read_image_bgr(p)
+        face = image_ref.mfn_lut()[image_ref.resize_bilinear_u8(img, (112, 112))]
+        with torch.no_grad():
+            return mobilefacenet_ref.forward(sd, torch.from_numpy(np.ascontiguousarray(face.transpose(2, 0, 1))).unsqueeze(0))[0].numpy()
+    e_ref = np.stack([emb_ref(p) for p in paths])
+    assert np.abs(e_hip - e_ref).max() < 1e-4
+    mean, thres = similarity_ref.ref_mean_and_thres(np.stack([emb_ref(p) for p in refs]))
+    dist, keep = similarity_ref.l2_filter(e_ref, mean, thres)
+    got_clean = set(os.listdir(tmp_path / "out" / "clean" / "class_a"))
+    margin = np.abs(dist - thres) > 1e-3
+    for p, k, mg in zip(paths, keep, margin):
+        if mg:
+            assert (os.path.basename(p) in got_clean) == bool(k)
+    with pytest.raises(Exception):
+        os.makedirs(tmp_path / "ref" / "class_c")
+        F.main(["--ud", str(tmp_path / "unf"), "--rd", str(tmp_path / "ref"), "--td", str(tmp_path / "o2"), "-m", wpath])
+
+
+def test_yolo_entry_point_and_loader(dev, tmp_path):
+    from face_detection_and_recognition_amd import detect_face_yolov5_face as E
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model
+    m = Model("yolov5n")
+    m.load_state_dict(synth_state_dict(m.state_dict(), 5))
+    wpath = str(tmp_path / "yolov5n-face.pt")
+    torch.save(m.state_dict(), wpath)
+    model = E.load_model(wpath, 0.4, 0.0, (640, 640), "hip:0")
+    frame = np.random.default_rng(1).integers(0, 256, (360, 640, 3), dtype=np.uint8)
+    dets = model(frame)
+    assert dets.ndim == 2 and dets.shape[1] == 5
+    with pytest.raises(NotImplementedError):
+        E.load_model(str(tmp_path / "x.onnx"), 0.4, 0.0, (640, 640), "hip")
+    bad = str(tmp_path / "yolov5s-face.pt")
+    torch.save({"not": "a state dict"}, bad)
+    with pytest.raises(Exception):
+        E.load_model(bad, 0.4, 0.0, (640, 640), "hip")
