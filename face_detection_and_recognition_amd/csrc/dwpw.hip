@@ -99,24 +99,28 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
 #pragma unroll
       for (int q = 0; q < P; ++q) a[q] = z;
       const int iy0 = oy * S - 1, ix0 = ox * S - 1;
+      // all 3 x WIN window loads are issued before the first FMA (one memory round trip per item, not three)
+      f32x4 x[3][WIN];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int iy = iy0 + ky;
         const bool vy = (unsigned)iy < (unsigned)p.H;
         const float* rowp = ib + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
-        f32x4 x[WIN];
 #pragma unroll
         for (int j = 0; j < WIN; ++j) {
           const int ix = ix0 + j;
           const bool v = vy && ((unsigned)ix < (unsigned)p.W);
           const f32x4 t = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
-          x[j] = v ? t : z;
+          x[ky][j] = v ? t : z;
         }
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
         const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * KCH + c];
         const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * KCH + c];
         const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * KCH + c];
 #pragma unroll
-        for (int q = 0; q < P; ++q) a[q] += x[q * S] * w0 + x[q * S + 1] * w1 + x[q * S + 2] * w2;
+        for (int q = 0; q < P; ++q) a[q] += x[ky][q * S] * w0 + x[ky][q * S + 1] * w1 + x[ky][q * S + 2] * w2;
       }
       const f32x4 sc = *(const f32x4*)&Ws[9 * KCH + c];
       const f32x4 bi = *(const f32x4*)&Ws[10 * KCH + c];

@@ -409,7 +409,7 @@ struct CropArgs {
 };
 
 __device__ __forceinline__ bool crop_one(const CropArgs& p, const float* d, float& x1, float& y1, float& x2,
-                                         float& y2, float& conf) {
+                                         float& y2, float& conf, float& perc) {
   if (p.fmt == 0) {
     conf = d[16];
     if (!(conf > p.det_thres)) return false;
@@ -420,7 +420,7 @@ __device__ __forceinline__ bool crop_one(const CropArgs& p, const float* d, floa
     x1 = d[0]; y1 = d[1]; x2 = d[2]; y2 = d[3];
   }
   const float area = (x2 - x1) * (y2 - y1);
-  const float perc = area / (float)(p.in_w * p.in_h);
+  perc = area / (float)(p.in_w * p.in_h);
   if (!(100.f * perc > p.area_thres)) return false;
   x1 = (x1 - p.pad_x) / p.gain; x2 = (x2 - p.pad_x) / p.gain;
   y1 = (y1 - p.pad_y) / p.gain; y2 = (y2 - p.pad_y) / p.gain;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256) void dets_to_crops_kernel(CropArgs p) {
       n = min(max(p.counts[f], 0), p.max_dets);
       D = p.dets + (long)f * p.max_dets * p.row;
       for (int i = 0; i < n; ++i) {
-        float x1, y1, x2, y2, c;
-        if (crop_one(p, D + (long)i * p.row, x1, y1, x2, y2, c)) ++cnt;
+        float x1, y1, x2, y2, c, pc;
+        if (crop_one(p, D + (long)i * p.row, x1, y1, x2, y2, c, pc)) ++cnt;
       }
     }
     scan[tid] = cnt;
@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void dets_to_crops_kernel(CropArgs p) {
     }
     int slot = base_s + scan[tid] - cnt;
     for (int i = 0; i < n; ++i) {
-      float x1, y1, x2, y2, c;
-      if (!crop_one(p, D + (long)i * p.row, x1, y1, x2, y2, c)) continue;
+      float x1, y1, x2, y2, c, pc;
+      if (!crop_one(p, D + (long)i * p.row, x1, y1, x2, y2, c, pc)) continue;
       if (slot < p.max_faces) {
         int x = (int)x1 + p.tx, y = (int)y1 + p.ty, xw = (int)x2 + p.bx, yh = (int)y2 + p.by;
         x = max(x, 0); y = max(y, 0); xw = min(xw, p.orig_w); yh = min(yh, p.orig_h);
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256) void dets_to_crops_kernel(CropArgs p) {
         it.dx = 0; it.dy = 0; it.dw = p.dst_w; it.dh = p.dst_h;
         if (it.sw <= 0 || it.sh <= 0) { it.dw = 0; it.dh = 0; }  // empty crop: canvas becomes pad colour
         p.items[slot] = it;
-        float* o = p.info + (long)slot * 6;
-        o[0] = (float)f; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = c;
+        float* o = p.info + (long)slot * 7;
+        o[0] = (float)f; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2; o[5] = c; o[6] = pc;
       }
       ++slot;
     }

@@ -55,7 +55,7 @@ class FacePipeline:
         B, H, W, _ = frames.shape
         cap = B * self.max_faces_per_frame
         items = torch.empty((cap, 9), dtype=torch.int32, device=self.dev)
-        info = torch.empty((cap, 6), dtype=torch.float32, device=self.dev)
+        info = torch.empty((cap, 7), dtype=torch.float32, device=self.dev)
         nf = torch.empty((1,), dtype=torch.int32, device=self.dev)
         iw, ih = self.det.input_size
         gain, px, py = scale_coords_params((iw, ih), (W, H))

@@ -174,8 +174,9 @@ int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int fr
  * (x1,y1,x2,y2,conf@4) in input pixels — get_bboxes_confs_areas (fde/modules/yolov5_face/onnx/onnx_utils.py:313-340).
  * Then scale_coords/clip/round (fde/modules/utils/image.py:62-99) and the crop arithmetic of
  * fde/face_extraction/extract_faces_from_dataset.py:289-303 (int(), offsets, clamp).  gain/pad are
- * scale_coords' values computed by the caller.  items[max_faces], face_info[max_faces][6] =
- * (frame, x1, y1, x2, y2, conf) in original-frame pixels (rounded), n_faces[1] = total found (the caller
+ * scale_coords' values computed by the caller.  items[max_faces], face_info[max_faces][7] =
+ * (frame, x1, y1, x2, y2 in original-frame pixels (rounded), conf, bbox area fraction of the model input as
+ * inference.py:37-44 reports it), n_faces[1] = total found (the caller
  * must check n_faces <= max_faces).  Faces are ordered by (frame, detection).
  */
 int fp_dets_to_crops(const float* dets, const int32_t* counts, int B, int max_dets, int row_floats, int fmt,
