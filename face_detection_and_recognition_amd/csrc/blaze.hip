@@ -204,6 +204,140 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
   }
 }
 
+// Persistent variant for the narrow blocks (Kpad <= 32, Cout <= 32: the 24-channel BlazeBlocks that carry ~60 % of
+// BlazeFace's bytes).  The per-tile kernel above starts every tile cold: weight staging, then the depthwise window
+// loads, each a full memory round trip with nothing else to do (rocprofv3: waves 50 % in s_waitcnt, 2.8 TB/s).
+// Here a workgroup stages the weights ONCE and walks tiles t = k*G + swz(block); the 3 x (3S+3) window of the NEXT
+// tile is loaded into registers right after the current tile's depthwise values are in LDS, so its HBM latency
+// hides under the MFMAs, the epilogue and the stores.  One lane = one (4-pixel group, 4-channel group) item.
+template <int S>
+__global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel(BlazeArgs p) {
+  constexpr int WIN = 3 * S + 3;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LDT = p.Kpad + 4, LDS_ = p.Cin + 4;
+  float* At = smem;                     // [TM][LDT]
+  float* St = At + TM * LDT;            // [TM][LDS_]
+  float* Ot = St + TM * LDS_;           // [TM][Cout]   (separate from At: one barrier less per tile)
+  float* Bs = Ot + TM * p.Cout;         // [Kpad/4][32][4]
+  float* Ws = Bs + p.Kpad * 32;         // [10][Cin]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+
+  for (int i = tid; i < (p.Kpad >> 2) * 32; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.wp + (long)i * 4);
+  for (int i = tid; i < (10 * p.Cin) >> 2; i += 256)
+    *(f32x4*)&Ws[i * 4] = (i * 4 < 9 * p.Cin) ? *(const f32x4*)(p.wd + (long)i * 4)
+                                              : *(const f32x4*)(p.bd + ((long)i * 4 - 9 * p.Cin));
+
+  const int KC4 = p.Kpad >> 2;
+  const int g = tid / KC4, c4 = tid - g * KC4;
+  const bool in_tile = tid < (TM / 4) * KC4;
+  const bool active = in_tile && c4 < p.C4;
+  const int r = g * 4, c = c4 * 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  // XCD-aware position of this block inside a window of G tiles (bijective for any G)
+  const int G = gridDim.x;
+  int pos;
+  {
+    const int b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
+    pos = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+
+  f32x4 x[3][WIN];
+  auto issue_loads = [&](long tile) {
+    long m = tile * TM + r;
+    m = m < p.M ? m : p.M - 4;
+    const unsigned mm = (unsigned)m;
+    const unsigned img = mm / (unsigned)p.OHW;
+    const unsigned rem = mm - img * (unsigned)p.OHW;
+    const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
+    const float* ib = p.in + (long)img * p.in_ns + c;
+    const int iy0 = S == 1 ? oy - 1 : 2 * oy, ix0 = S == 1 ? ox - 1 : 2 * ox;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = iy0 + ky;
+      const bool vy = (unsigned)iy < (unsigned)p.H;
+      const float* rowp = ib + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) {
+        const int ix = ix0 + j;
+        const bool v = vy && ((unsigned)ix < (unsigned)p.W);
+        const f32x4 t = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
+        x[ky][j] = v ? t : z;
+      }
+    }
+  };
+
+  long tile = pos;
+  if (tile < p.ntiles && active) issue_loads(tile);
+  __syncthreads();  // weights staged
+  const float bias_n = lr < p.Cout ? p.bp[lr] : 0.f;
+  for (long k = 0; tile < p.ntiles; ++k) {
+    // depthwise + shortcut from the prefetched window
+    if (active) {
+      f32x4 acc[4] = {z, z, z, z}, sc[4];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * p.Cin + c];
+        const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * p.Cin + c];
+        const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * p.Cin + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += x[ky][q * S] * w0 + x[ky][q * S + 1] * w1 + x[ky][q * S + 2] * w2;
+      }
+      const f32x4 bias = *(const f32x4*)&Ws[9 * p.Cin + c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (S == 1) {
+          sc[q] = x[1][q + 1];  // centre tap = x itself
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)  // rows 0,1 x cols 2q,2q+1 = the 2x2 max-pool window
+            sc[q][e] = fmaxf(fmaxf(x[0][2 * q][e], x[0][2 * q + 1][e]), fmaxf(x[1][2 * q][e], x[1][2 * q + 1][e]));
+        }
+        *(f32x4*)&At[(r + q) * LDT + c] = acc[q] + bias;
+        *(f32x4*)&St[(r + q) * LDS_ + c] = sc[q];
+      }
+    } else if (in_tile) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(f32x4*)&At[(r + q) * LDT + c] = z;  // zero padding columns of the K dimension
+    }
+    __syncthreads();
+    const long next = (k + 1) * G + pos;
+    if (next < p.ntiles && active) issue_loads(next);  // in flight during MFMA + epilogue + stores
+
+    f32x16 macc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) macc[i] = 0.f;
+    const float* arow = &At[(wave * 32 + lr) * LDT + 4 * h];
+    for (int kq = 0; kq < (p.Kpad >> 3); ++kq) {
+      const f32x4 a = *(const f32x4*)(arow + kq * 8);
+      const f32x4 b = *(const f32x4*)&Bs[((kq * 2 + h) * 32 + lr) * 4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], macc, 0, 0, 0);
+    }
+    if (lr < p.Cout) {
+      const bool has_sc = lr < p.res_C;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        float v = macc[reg] + bias_n;
+        if (has_sc) v += St[row * LDS_ + lr];
+        Ot[row * p.Cout + lr] = v > 0.f ? v : 0.f;
+      }
+    }
+    __syncthreads();  // Ot complete; At / St free for the next tile
+    {
+      const long m0 = tile * TM;
+      const long rows_left = p.M - m0;
+      const int nrows = rows_left < TM ? (int)rows_left : TM;
+      const int n4 = nrows * p.Cout / 4;
+      float* obase = p.out + m0 * p.Cout;
+      for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+    }
+    tile = next;
+  }
+}
+
 }  // namespace
 
 size_t fp_blazeblock_lds_bytes(int Cin, int Cout) {
@@ -241,6 +375,20 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
   a.M = (long)op.N * a.OHW;
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;
   a.ntiles = fp_ceil_div(a.M, TM);
+  if (a.Kpad <= 32 && a.Npad == 32 && a.ntiles >= 2048) {
+    // persistent kernel: 3 (stride 1) / 2 (stride 2) resident workgroups per CU, each striding over the tiles
+    const size_t plds = 4 * ((size_t)TM * (a.Kpad + 4) + (size_t)TM * (op.Cin + 4) + (size_t)TM * op.Cout +
+                             (size_t)a.Kpad * 32 + (size_t)10 * op.Cin);
+    const int per_cu = op.stride == 1 ? 3 : 2;
+    int G = 256 * per_cu;
+    if (G > a.ntiles) G = a.ntiles;
+    if (plds <= 64 * 1024) {
+      if (op.stride == 1) hipLaunchKernelGGL((blazeblock_persist_kernel<1>), dim3(G), dim3(256), plds, s, a);
+      else hipLaunchKernelGGL((blazeblock_persist_kernel<2>), dim3(G), dim3(256), plds, s, a);
+      FP_CHECK_LAUNCH();
+      return FP_OK;
+    }
+  }
   dim3 grid((unsigned)a.ntiles), block(256);
 #define FP_BB_CASE(NBV)                                                                                     \
   case NBV:                                                                                                 \

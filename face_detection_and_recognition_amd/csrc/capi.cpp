@@ -139,7 +139,11 @@ const char* fp_op_kernel_name(const fp_op* op) {
               op->out_off % 4 == 0 && op->in_ns % 4 == 0 && op->out_ns % 4 == 0) ? "copy4_kernel" : "copy_kernel";
     case FP_OP_L2NORM: return "l2norm_kernel";
     case FP_OP_BLAZEBLOCK:
-      snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
+      if (fp_round_up(op->Cin, 8) <= 32 && fp_round_up(op->Cout, 32) == 32 &&
+          fp_ceil_div((long)op->N * op->OH * op->OW, 128) >= 2048)
+        snprintf(buf, sizeof(buf), "blazeblock_persist_kernel<%d>", op->stride);
+      else
+        snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
     case FP_OP_DWPW:
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
