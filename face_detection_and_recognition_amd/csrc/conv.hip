@@ -589,8 +589,10 @@ static bool conv_vec_epilogue(const fp_op& op) {
   return ve;
 }
 
+// K bound below which pointwise-dense ops take 64-wide N tiles (NB = 2, occupancy 4).  Measured equal in time to
+// NB = 4 for 64 -> 128 but with the A panel fetched twice (rocprofv3 FETCH_SIZE 2x): disabled.
 #ifndef FP_PWD_NB2_MAX_K
-#define FP_PWD_NB2_MAX_K 64
+#define FP_PWD_NB2_MAX_K 0
 #endif
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd) {
   *vec = ((op.Cin % 4 == 0) && (op.in_ld % 4 == 0) && (op.in_off % 4 == 0) && (op.in_ns % 4 == 0)) ? 1 : 0;
