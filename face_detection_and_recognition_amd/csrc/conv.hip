@@ -14,6 +14,8 @@
 // k-steps: lane (r = lane&31, h = lane>>5) holds A[r][8g+4h .. 8g+4h+3] and B[8g+4h .. +3][r], i.e. k-step t
 // multiplies k = 8g+t (h=0) and 8g+4+t (h=1) — a permutation of the k order, which a sum does not care about.
 // LDS row stride for A is 36 floats (144 B): 16 consecutive rows hit 16 distinct 16-B slots -> conflict free.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
   }
 
   // Epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  if (p.vec_epi) {
+  if (PWD || p.vec_epi) {
     // Vector epilogue: acc*scale+bias goes through LDS (PW 32-column blocks per pass) so that every lane then
     // owns 4 consecutive channels of one pixel: residual loads, activation and the output stores are 16-byte,
     // fully coalesced accesses (256 B per row for PW = 2) instead of 4-byte stores in 128-B segments.
@@ -218,6 +220,95 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
     const unsigned uOHW = (unsigned)p.OHW;
     const int act = p.act, res_mode = p.res_mode;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const bool silu = act == FP_ACT_SILU, has_res = res_mode != FP_RES_NONE, after = res_mode == FP_RES_ADD_AFTER_ACT;
+    // Store loop of one pass.  Two rules shape it (both measured, tools/lab/README.md):
+    //  * vmcnt counts loads AND stores of a wave in one queue, so a global load inside the store loop (slope,
+    //    residual) makes every iteration wait for all earlier stores to be acknowledged (~1 us each under load).
+    //    All loads of a batch of BATCH float4s are therefore issued before its first store.
+    //  * the activation is branch-free: x > 0 ? x : x*s + 0 with s = 1 (none), 0 (relu), slope (prelu); a switch
+    //    on the runtime act code costs ~8 scalar branches per element.  SiLU and "has residual" select one of four
+    //    straight-line copies of the loop instead.
+    constexpr int NIT = ROWS * F4_PER_ROW / 256;
+    static_assert(ROWS * F4_PER_ROW % 256 == 0, "whole iterations");
+    constexpr int BATCH = NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : (NIT % 2 == 0 ? 2 : 1));
+    static_assert(NIT % BATCH == 0, "batches tile the pass");
+    constexpr bool C4_FIXED = 256 % F4_PER_ROW == 0;   // a lane keeps its channel group for all of its rows
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+    auto neg_slope = [&](int n) -> f32x4 {
+      if (act == FP_ACT_PRELU) return n < p.Cout ? *(const f32x4*)(p.slope + n) : z4;
+      return act == FP_ACT_RELU ? z4 : one4;
+    };
+    f32x4 sl_fixed = z4;
+    if (C4_FIXED) sl_fixed = neg_slope(n0 + (tid % F4_PER_ROW) * 4);
+    auto store_rows = [&](long mp, auto silu_c, auto res_c) {
+      constexpr bool SILU = decltype(silu_c)::value, RES = decltype(res_c)::value;
+      unsigned img_b = 0, pix_b = 0;
+      if (!PWD) {
+        img_b = (unsigned)mp / uOHW;
+        pix_b = (unsigned)mp - img_b * uOHW;
+      }
+#pragma unroll
+      for (int jb = 0; jb < NIT; jb += BATCH) {
+        f32x4 rr[BATCH], sl[BATCH];
+        long ooff[BATCH];
+        bool ok[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {   // addresses + every load of the batch
+          const int f = tid + 256 * (jb + j);
+          const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+          const long m = mp + row;
+          const int n = n0 + c4 * 4;
+          ok[j] = m < p.M && n < p.Cout;
+          sl[j] = C4_FIXED ? sl_fixed : neg_slope(n);
+          rr[j] = z4;
+          if (PWD) {
+            ooff[j] = m * p.out_ld + n;
+            if (RES && ok[j] && n < p.res_C4) rr[j] = *(const f32x4*)(p.res + m * p.res_ld + n);
+          } else {
+            unsigned img = img_b, pix = pix_b + (unsigned)row;
+            if (uOHW >= (unsigned)BM) {
+              if (pix >= uOHW) { pix -= uOHW; ++img; }
+            } else {
+              const unsigned qd = pix / uOHW;
+              img += qd;
+              pix -= qd * uOHW;
+            }
+            ooff[j] = (long)img * p.out_ns + (long)pix * p.out_ld + n;
+            if (RES && ok[j] && n < p.res_C4) {
+              if (res_mode == FP_RES_POOL2_BEFORE_ACT) {
+                const unsigned oy = pix / (unsigned)p.OW, ox = pix - oy * (unsigned)p.OW;
+                const float* r0 = p.res + (long)img * p.res_ns + ((long)(2 * oy) * p.res_W + 2 * ox) * p.res_ld + n;
+                const float* r1 = r0 + (long)p.res_W * p.res_ld;
+                const f32x4 a0 = *(const f32x4*)r0, a1 = *(const f32x4*)(r0 + p.res_ld);
+                const f32x4 b0 = *(const f32x4*)r1, b1 = *(const f32x4*)(r1 + p.res_ld);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rr[j][e] = fmaxf(fmaxf(a0[e], a1[e]), fmaxf(b0[e], b1[e]));
+              } else {
+                rr[j] = *(const f32x4*)(p.res + (long)img * p.res_ns + (long)pix * p.res_ld + n);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {   // LDS -> activation -> 16-byte stores, nothing to wait for in between
+          const int f = tid + 256 * (jb + j);
+          const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+          if (!ok[j]) continue;
+          const f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pre = (RES && !after) ? rr[j][e] : 0.f;
+            const float x = RES ? v[e] + pre : v[e];
+            float y;
+            if (SILU) y = x / (1.0f + expf(-x));
+            else y = x > 0.f ? x : __builtin_fmaf(x, sl[j][e], 0.0f);
+            o[e] = (RES && after) ? y + rr[j][e] : y;
+          }
+          *(f32x4*)(p.out + ooff[j]) = o;
+        }
+      }
+    };
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       if (pass) __syncthreads();  // the previous pass has been read out
@@ -234,56 +325,12 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
       }
       __syncthreads();
       const long mp = m0 + pass * ROWS;
-      const unsigned img_b = (unsigned)mp / uOHW;
-      const unsigned pix_b = (unsigned)mp - img_b * uOHW;
-      for (int f = tid; f < ROWS * F4_PER_ROW; f += 256) {
-        const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
-        const long m = mp + row;
-        const int n = n0 + c4 * 4;
-        if (m >= p.M || n >= p.Cout) continue;
-        f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
-        f32x4 r = z4;
-        if (PWD) {
-          if (res_mode != FP_RES_NONE && n < p.res_C4) r = *(const f32x4*)(p.res + m * p.res_ld + n);
-          f32x4 sl = z4;
-          if (act == FP_ACT_PRELU) sl = *(const f32x4*)(p.slope + n);
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o[e] = (res_mode == FP_RES_ADD_AFTER_ACT) ? apply_act(v[e], act, sl[e]) + r[e]
-                                                      : apply_act(v[e] + r[e], act, sl[e]);
-          *(f32x4*)(p.out + m * p.out_ld + n) = o;
-          continue;
-        }
-        unsigned img = img_b, pix = pix_b + (unsigned)row;
-        if (uOHW >= (unsigned)BM) {
-          if (pix >= uOHW) { pix -= uOHW; ++img; }
-        } else {
-          const unsigned qd = pix / uOHW;
-          img += qd;
-          pix -= qd * uOHW;
-        }
-        if (res_mode != FP_RES_NONE && n < p.res_C4) {
-          if (res_mode == FP_RES_POOL2_BEFORE_ACT) {
-            const unsigned oy = pix / (unsigned)p.OW, ox = pix - oy * (unsigned)p.OW;
-            const float* r0 = p.res + (long)img * p.res_ns + ((long)(2 * oy) * p.res_W + 2 * ox) * p.res_ld + n;
-            const float* r1 = r0 + (long)p.res_W * p.res_ld;
-            const f32x4 a0 = *(const f32x4*)r0, a1 = *(const f32x4*)(r0 + p.res_ld);
-            const f32x4 b0 = *(const f32x4*)r1, b1 = *(const f32x4*)(r1 + p.res_ld);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(a0[e], a1[e]), fmaxf(b0[e], b1[e]));
-          } else {
-            r = *(const f32x4*)(p.res + (long)img * p.res_ns + (long)pix * p.res_ld + n);
-          }
-        }
-        f32x4 sl = z4;
-        if (act == FP_ACT_PRELU) sl = *(const f32x4*)(p.slope + n);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = (res_mode == FP_RES_ADD_AFTER_ACT) ? apply_act(v[e], act, sl[e]) + r[e]
-                                                    : apply_act(v[e] + r[e], act, sl[e]);
-        *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + n) = o;
+      if (silu) {
+        if (has_res) store_rows(mp, std::true_type{}, std::true_type{});
+        else store_rows(mp, std::true_type{}, std::false_type{});
+      } else {
+        if (has_res) store_rows(mp, std::false_type{}, std::true_type{});
+        else store_rows(mp, std::false_type{}, std::false_type{});
       }
     }
     return;
