@@ -13,6 +13,8 @@
 //   phase 2  4 waves x 32 rows: v_mfma_f32_32x32x2_f32 against the chunk of packed projection weights in LDS,
 //            accumulating over the chunks in registers;
 // then the conv.hip vector epilogue (acc*s+b through LDS, 16-B residual loads and stores).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -29,7 +31,26 @@ struct DwPwArgs {
   int Npad, OHW, has_res, has_slope;
   long M;
   int ntiles;
+#ifdef FP_DWPW_STAMPS
+  unsigned long long* stamps;   // lab builds only (tools/lab/dwpw_lab.hip): s_memtime per phase of the first units
+#endif
 };
+
+// In-kernel phase stamps of the persistent kernel, compiled in by the lab harness only.
+#ifdef FP_DWPW_STAMPS
+#define FP_DWPW_NUNIT 24
+#define FP_DWPW_NSTAMP 6
+#define DWPW_STAMP(k)                                                                                  \
+  do {                                                                                                 \
+    if (p.stamps && blockIdx.x < 4 && unit < FP_DWPW_NUNIT && (threadIdx.x & 63) == 0) {               \
+      unsigned long long tt_;                                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");                      \
+      p.stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) * FP_DWPW_NUNIT + unit) * FP_DWPW_NSTAMP + (k)] = tt_; \
+    }                                                                                                  \
+  } while (0)
+#else
+#define DWPW_STAMP(k) do { } while (0)
+#endif
 
 constexpr int TM = 128;
 constexpr int KCH = 64;
@@ -189,7 +210,304 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant (even OH/OW, Cout = 64 or 128: every 56x56 .. 14x14 block of
+// Mobile-FaceNet).  The per-tile kernel above starts each 64-channel chunk cold: the projection weights are staged
+// by a load -> wait -> ds_write loop (one L2 round trip per 256 float4s), then each depthwise item waits for its own
+// window, and nothing overlaps the MFMAs (rocprofv3 r01: 2.7-4.2 TB/s algorithmic, MFMA pipe < 30 % busy).
+// Here a workgroup keeps the depthwise parameters of all G channels in LDS, walks tiles t = k*grid + pos, and
+// treats (tile, 32-channel chunk) as the unit of a two-stage pipeline: the window and the projection-weight chunk
+// of unit u+1 are loaded into registers right after unit u's depthwise values are in LDS, so their latency hides
+// under unit u's MFMAs (and, at a tile boundary, under the epilogue and its stores).
+// A tile is 32 patches of 2x2 output pixels (row r of the tile = patch r>>2, pixel (r>>1)&1, r&1): one lane = one
+// (patch, 4-channel group) item whose (S+3)^2 window feeds all four outputs -- 16 loads for 4 outputs at stride 1
+// whatever OW is (a 1x4 strip needs OW % 4 == 0 and 18 loads), and exactly one item per lane and unit.
+constexpr int PKC = 32;
+constexpr int PLDT = PKC + 4;
+
+template <int NB, int S>
+__global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int WR = S + 3;   // window rows = window columns
+  constexpr int PW = 2;
+  constexpr int LDO = PW * 32 + 4;
+  constexpr int F4_PER_ROW = PW * 8;
+  constexpr int AB = TM * PLDT + PKC * BN, ST = TM * LDO;
+  constexpr int WS0 = AB > ST ? AB : ST;
+  static_assert(NB % 2 == 0, "instantiated for Cout 64 / 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* At = smem;                 // [TM][PLDT]           depthwise output of the current unit
+  float* Bs = smem + TM * PLDT;     // [PKC/4][BN][4]       projection weights of the current unit
+  float* Ws = smem + WS0;           // [12][G]              taps 0..8, scale, bias, slope (ones without PReLU)
+  int* Mrow = (int*)(Ws + 12 * p.G);  // [TM]               output pixel index of each tile row (-1: past the end)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const int Gc = p.G;
+
+  for (int i = tid; i < 3 * Gc; i += 256) {   // 12*G/4 float4s
+    const int row = (i * 4) / Gc;
+    f32x4 v = {1.f, 1.f, 1.f, 1.f};
+    if (row < 11 || p.has_slope) v = *(const f32x4*)(p.dwp + (long)i * 4);
+    *(f32x4*)&Ws[i * 4] = v;
+  }
+
+  // XCD-aware position of this block inside a window of gridDim.x tiles (bijective for any grid size)
+  const int NBLK = gridDim.x;
+  int pos;
+  {
+    const int b = blockIdx.x, q = NBLK / 8, rr = NBLK % 8, xcd = b & 7, k = b >> 3;
+    pos = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int nch = Gc / PKC;
+  const int c = (tid & 7) * 4;      // this lane's 4 channels inside a chunk
+  const int g = tid >> 3;           // this lane's patch inside the tile
+  const unsigned PWc = (unsigned)p.OW >> 1, PPI = ((unsigned)p.OH >> 1) * PWc;   // patches per row / per image
+  const unsigned npatch = (unsigned)p.N * PPI;
+
+  // prefetch side: window of this lane's patch in tile `ptile`, decoded once per tile (the chunks of a tile share it):
+  // clamped row / column offsets and the in-image mask, so that a unit's loads cost one 64-bit add each
+  long ptile = pos;
+  int pch = 0;
+  long rowoff[WR];
+  int coloff[WR];
+  unsigned xmask = 0;                // bit wy*WR+wx: window position inside the image (else zero padding)
+  auto decode = [&](long tile) {
+    unsigned pi = (unsigned)tile * 32u + (unsigned)g;
+    pi = pi < npatch ? pi : npatch - 1;   // tail patches recompute the last one; they are never stored
+    const unsigned img = pi / PPI, rem = pi - img * PPI;
+    const unsigned py = rem / PWc, px = rem - py * PWc;
+    const int iy0 = (int)(2 * py) * S - 1, ix0 = (int)(2 * px) * S - 1;
+    unsigned rowv = 0, colv = 0;
+#pragma unroll
+    for (int w = 0; w < WR; ++w) {
+      const int iy = iy0 + w, ix = ix0 + w;
+      rowoff[w] = (long)img * p.in_ns + c + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+      coloff[w] = min(max(ix, 0), p.W - 1) * p.in_ld;
+      if ((unsigned)iy < (unsigned)p.H) rowv |= 1u << w;
+      if ((unsigned)ix < (unsigned)p.W) colv |= 1u << w;
+    }
+    xmask = 0;
+#pragma unroll
+    for (int w = 0; w < WR; ++w)
+      if ((rowv >> w) & 1u) xmask |= colv << (w * WR);
+  };
+  f32x4 x[WR][WR];
+  f32x4 wreg[NB];
+  auto issue_loads = [&](int ch) {   // every load of the unit back to back: one memory round trip
+    const int g0 = ch * PKC;
+    const float* ib = p.in + g0;
+    // raw (clamped-address) values; the padding mask is applied when the window is consumed, one unit later -- a
+    // select right here would make the wave wait for the loads before it starts the MFMAs they should hide under
+#pragma unroll
+    for (int wy = 0; wy < WR; ++wy)
+#pragma unroll
+      for (int wx = 0; wx < WR; ++wx) x[wy][wx] = *(const f32x4*)(ib + rowoff[wy] + coloff[wx]);
+    const float* wb = p.pwp + (long)g0 * BN;   // Npad == BN: the chunk's [PKC/4][BN][4] block is contiguous
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wreg[j] = *(const f32x4*)(wb + (long)(tid + 256 * j) * 4);
+  };
+
+  if (ptile < p.ntiles) {
+    decode(ptile);
+    issue_loads(0);
+  }
+
+  // per-column projection affine (lane constants for the whole kernel)
+  const float* pscale = p.pwp + (long)Gc * p.Npad;
+  const float* pbias = pscale + ((p.Cout + 3) & ~3);
+  float sc[NB], bi[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = nb * 32 + lr;
+    const int nn = n < p.Cout ? n : 0;
+    sc[nb] = pscale[nn];
+    bi[nb] = pbias[nn];
+  }
+  __syncthreads();   // Ws staged
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  long tile = pos;
+  int ch = 0;
+  int unit = -1;
+  (void)unit;
+  while (tile < p.ntiles) {
+    ++unit;
+    DWPW_STAMP(0);
+    if (ch == 0 && tid < TM) {   // output pixel of every tile row, for the epilogue (visible after this unit's barrier)
+      const unsigned pi = (unsigned)tile * 32u + ((unsigned)tid >> 2);
+      int m = -1;
+      if (pi < npatch) {
+        const unsigned img = pi / PPI, rem = pi - img * PPI;
+        const unsigned py = rem / PWc, px = rem - py * PWc;
+        m = (int)(img * (unsigned)p.OHW + (2 * py + ((tid >> 1) & 1)) * (unsigned)p.OW + 2 * px + (tid & 1));
+      }
+      Mrow[tid] = m;
+    }
+    // phase 1: depthwise + affine + PReLU of this unit from the prefetched window -> At; weight chunk -> Bs
+    {
+      const int gc = ch * PKC + c;
+      f32x4 a[4] = {z, z, z, z};
+      // zero padding: only the window's border can fall outside the image (S = 2, even H/W: only its top / left)
+#pragma unroll
+      for (int wy = 0; wy < WR; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < WR; ++wx) {
+          const bool edge = wy == 0 || wx == 0 || (S == 1 && (wy == WR - 1 || wx == WR - 1));
+          if (edge) x[wy][wx] = ((xmask >> (wy * WR + wx)) & 1u) ? x[wy][wx] : z;
+        }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * Gc + gc];
+        const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * Gc + gc];
+        const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * Gc + gc];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int wy = (q >> 1) * S + ky, wx = (q & 1) * S;
+          a[q] += x[wy][wx] * w0 + x[wy][wx + 1] * w1 + x[wy][wx + 2] * w2;
+        }
+      }
+      const f32x4 dsc = *(const f32x4*)&Ws[9 * Gc + gc];
+      const f32x4 dbi = *(const f32x4*)&Ws[10 * Gc + gc];
+      const f32x4 dsl = *(const f32x4*)&Ws[11 * Gc + gc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = a[q] * dsc + dbi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * dsl[e];
+        *(f32x4*)&At[(g * 4 + q) * PLDT + c] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *(f32x4*)&Bs[(tid + 256 * j) * 4] = wreg[j];
+    }
+    DWPW_STAMP(1);
+    __syncthreads();
+    DWPW_STAMP(2);
+
+    // prefetch the next unit (same tile, next chunk -- or the first chunk of this block's next tile)
+    if (++pch == nch) {
+      pch = 0;
+      ptile += NBLK;
+      if (ptile < p.ntiles) decode(ptile);
+    }
+    if (ptile < p.ntiles) issue_loads(pch);
+    DWPW_STAMP(3);
+
+    // phase 2: projection MFMAs of this unit
+    {
+      const float* arow = &At[(wave * 32 + lr) * PLDT + 4 * h];
+#pragma unroll
+      for (int kq = 0; kq < PKC / 8; ++kq) {
+        const f32x4 av = *(const f32x4*)(arow + kq * 8);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const f32x4 bv = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[nb], 0, 0, 0);
+        }
+      }
+    }
+    DWPW_STAMP(4);
+    __syncthreads();   // At / Bs are rewritten by the next unit (or by the epilogue staging)
+    DWPW_STAMP(5);
+    if (++ch < nch) continue;
+
+    // epilogue of the tile: acc*scale+bias through LDS (64 columns per pass), 16-B residual loads and stores
+    const bool full_tile = ((unsigned)tile + 1u) * 32u <= npatch && p.Cout == BN;   // uniform
+    if (full_tile) {
+      // Straight-line epilogue.  vmcnt is ONE in-order counter for a wave's loads and stores, so the residual loads
+      // of the second pass are issued BEFORE the first pass's stores (waiting for them then leaves the 8 stores in
+      // flight: a counted vmcnt(8) instead of a drain), and no load ever follows a store it has to wait behind.
+      constexpr int PASSES = NB / PW;
+      auto fast = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        const int row0 = tid >> 4, cc = (tid & 15) * 4;   // 16 float4s per 64-column row; rows row0 + 16*j
+        long mo[8];
+        f32x4 rr[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mo[j] = (long)Mrow[row0 + 16 * j];
+        if (RES) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rr[j] = *(const f32x4*)(p.res + mo[j] * p.res_ld + cc);
+        }
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+          if (pass) __syncthreads();
+#pragma unroll
+          for (int q = 0; q < PW; ++q) {
+            const int nb = pass * PW + q;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+              smem[row * LDO + q * 32 + lr] = acc[nb][reg] * sc[nb] + bi[nb];
+              acc[nb][reg] = 0.f;
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = *(const f32x4*)&smem[(row0 + 16 * j) * LDO + cc];
+            if (RES) v[j] += rr[j];
+          }
+          if (RES && pass + 1 < PASSES) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr[j] = *(const f32x4*)(p.res + mo[j] * p.res_ld + (pass + 1) * PW * 32 + cc);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) *(f32x4*)(p.out + mo[j] * p.out_ld + pass * PW * 32 + cc) = v[j];
+        }
+      };
+      if (p.has_res) fast(std::true_type{});
+      else fast(std::false_type{});
+      __syncthreads();   // staging read out; At / Bs free for the next tile's first unit
+      ch = 0;
+      tile += NBLK;
+      continue;
+    }
+    // last (partial) tile / Cout below the padded width: bounds-checked read-out
+#pragma unroll
+    for (int pass = 0; pass < NB / PW; ++pass) {
+      if (pass) __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PW; ++q) {
+        const int nb = pass * PW + q;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          smem[row * LDO + q * 32 + lr] = acc[nb][reg] * sc[nb] + bi[nb];
+          acc[nb][reg] = 0.f;
+        }
+      }
+      __syncthreads();
+      const int ncol0 = pass * PW * 32;
+      for (int f = tid; f < TM * F4_PER_ROW; f += 256) {
+        const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+        const int n = ncol0 + c4 * 4;
+        const int m = Mrow[row];
+        if (m < 0 || n >= p.Cout) continue;
+        f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
+        if (p.has_res) v += *(const f32x4*)(p.res + (long)m * p.res_ld + n);
+        *(f32x4*)(p.out + (long)m * p.out_ld + n) = v;
+      }
+    }
+    __syncthreads();   // staging read out; At / Bs free for the next tile's first unit
+    ch = 0;
+    tile += NBLK;
+  }
+}
+
 }  // namespace
+
+#ifdef FP_DWPW_STAMPS
+static unsigned long long* g_dwpw_stamps = nullptr;
+#endif
 
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
   // op: KH = KW = 3, pad 1, stride 1|2, Cin = G (multiple of 64), Cout multiple of 4 and <= 128;
@@ -222,8 +540,36 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
   a.M = (long)op.N * OHW;
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;
   a.ntiles = fp_ceil_div(a.M, TM);
+#ifdef FP_DWPW_STAMPS
+  a.stamps = g_dwpw_stamps;
+#endif
   const int NB = a.Npad / 32;
   const int P = (op.OW % 4 == 0) ? 4 : (op.OW % 2 == 0) ? 2 : 1;
+  // persistent pipelined kernel over tiles of 32 2x2 patches, 2 resident workgroups per CU.  Cout = 128 at stride 2
+  // (a 5x5 window + 4 accumulators per lane) spills and measured slower than the per-tile kernel: left to that one.
+  if ((NB == 2 || (NB == 4 && op.stride == 1)) && op.OH % 2 == 0 && op.OW % 2 == 0 &&
+      (op.stride == 1 || (op.H % 2 == 0 && op.W % 2 == 0)) && a.M >= 1024L * TM) {
+    const size_t ab = (size_t)TM * PLDT + (size_t)PKC * NB * 32, st = (size_t)TM * (2 * 32 + 4);
+    const size_t plds = 4 * ((ab > st ? ab : st) + (size_t)12 * a.G + TM);
+    if (plds <= 80 * 1024) {
+      DwPwArgs b = a;
+      b.ntiles = (int)fp_ceil_div((long)op.N * (op.OH / 2) * (op.OW / 2), 32);
+      int nblk = 512;
+      if (nblk > b.ntiles) nblk = b.ntiles;
+#define FP_DWPW_PERSIST(NBV, SV)                                                                                \
+  do {                                                                                                          \
+    if (plds > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute((const void*)dwpw_persist_kernel<NBV, SV>,                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                         \
+    hipLaunchKernelGGL((dwpw_persist_kernel<NBV, SV>), dim3(nblk), dim3(256), plds, s, b);                      \
+  } while (0)
+      if (NB == 2) { if (op.stride == 1) FP_DWPW_PERSIST(2, 1); else FP_DWPW_PERSIST(2, 2); }
+      else FP_DWPW_PERSIST(4, 1);
+#undef FP_DWPW_PERSIST
+      FP_CHECK_LAUNCH();
+      return FP_OK;
+    }
+  }
   dim3 grid((unsigned)a.ntiles), block(256);
   const size_t lds = 4 * ((size_t)TM * LDT + (size_t)KCH * NB * 32 + 12 * KCH);
 #define FP_DWPW_LAUNCH(NBV, PV, SV)                                                                        \
