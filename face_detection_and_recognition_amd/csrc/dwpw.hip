@@ -269,7 +269,13 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 
   // prefetch side: window of this lane's patch in tile `ptile`, decoded once per tile (the chunks of a tile share it):
   // clamped row / column offsets and the in-image mask, so that a unit's loads cost one 64-bit add each
-  long ptile = pos;
+  // Round k hands tile k*NBLK + pos to this block (XCD-contiguous); the last, partial round goes to the blocks with
+  // the lowest raw indices instead, which the dispatcher spreads over all XCDs and distinct CUs -- with pos, whole XCDs
+  // would take the extra tile on both of their resident workgroups (8 tiles per CU against 6 on the 14x14 layers).
+  const long full_rounds = p.ntiles / NBLK;
+  auto tile_of = [&](long k) { return k * NBLK + (k < full_rounds ? pos : (int)blockIdx.x); };
+  long pk = 0, ck = 0;
+  long ptile = tile_of(0);
   int pch = 0;
   long rowoff[WR];
   int coloff[WR];
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-  long tile = pos;
+  long tile = tile_of(0);
   int ch = 0;
   int unit = -1;
   (void)unit;
@@ -394,10 +400,13 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
     // prefetch the next unit (same tile, next chunk -- or the first chunk of this block's next tile)
     if (++pch == nch) {
       pch = 0;
-      ptile += NBLK;
+      ptile = tile_of(++pk);
       if (ptile < p.ntiles) decode(ptile);
     }
     if (ptile < p.ntiles) issue_loads(pch);
+#ifdef FP_DWPW_LAB_WAIT_EARLY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lab: raw latency of the unit's loads, nothing overlapped
+#endif
     DWPW_STAMP(3);
 
     // phase 2: projection MFMAs of this unit
@@ -415,6 +424,9 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
       }
     }
     DWPW_STAMP(4);
+#ifdef FP_DWPW_STAMPS
+    if (p.stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lab: expose the prefetch's residual latency
+#endif
     __syncthreads();   // At / Bs are rewritten by the next unit (or by the epilogue staging)
     DWPW_STAMP(5);
     if (++ch < nch) continue;
@@ -426,17 +438,19 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
       // of the second pass are issued BEFORE the first pass's stores (waiting for them then leaves the 8 stores in
       // flight: a counted vmcnt(8) instead of a drain), and no load ever follows a store it has to wait behind.
       constexpr int PASSES = NB / PW;
+      constexpr int EB = NB == 4 ? 4 : 8;          // float4s per lane and group (register budget: 2 x EB float4s live)
+      constexpr int SUBS = 8 / EB, NG = PASSES * SUBS;
       auto fast = [&](auto res_c) {
         constexpr bool RES = decltype(res_c)::value;
         const int row0 = tid >> 4, cc = (tid & 15) * 4;   // 16 float4s per 64-column row; rows row0 + 16*j
-        long mo[8];
-        f32x4 rr[8], v[8];
+        f32x4 rr[EB], v[EB];
+        auto load_res = [&](int grp) {   // group = (pass, sub): rows row0 + 16*(sub*EB + j), columns pass*64 + cc
+          const int pass = grp / SUBS, sub = grp % SUBS;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mo[j] = (long)Mrow[row0 + 16 * j];
-        if (RES) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) rr[j] = *(const f32x4*)(p.res + mo[j] * p.res_ld + cc);
-        }
+          for (int j = 0; j < EB; ++j)
+            rr[j] = *(const f32x4*)(p.res + (long)Mrow[row0 + 16 * (sub * EB + j)] * p.res_ld + pass * PW * 32 + cc);
+        };
+        if (RES) load_res(0);
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
           if (pass) __syncthreads();
@@ -452,23 +466,25 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
           }
           __syncthreads();
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            v[j] = *(const f32x4*)&smem[(row0 + 16 * j) * LDO + cc];
-            if (RES) v[j] += rr[j];
-          }
-          if (RES && pass + 1 < PASSES) {
+          for (int sub = 0; sub < SUBS; ++sub) {
+            const int grp = pass * SUBS + sub;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rr[j] = *(const f32x4*)(p.res + mo[j] * p.res_ld + (pass + 1) * PW * 32 + cc);
-          }
+            for (int j = 0; j < EB; ++j) {
+              v[j] = *(const f32x4*)&smem[(row0 + 16 * (sub * EB + j)) * LDO + cc];
+              if (RES) v[j] += rr[j];
+            }
+            if (RES && grp + 1 < NG) load_res(grp + 1);   // before this group's stores (see above)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) *(f32x4*)(p.out + mo[j] * p.out_ld + pass * PW * 32 + cc) = v[j];
+            for (int j = 0; j < EB; ++j)
+              *(f32x4*)(p.out + (long)Mrow[row0 + 16 * (sub * EB + j)] * p.out_ld + pass * PW * 32 + cc) = v[j];
+          }
         }
       };
       if (p.has_res) fast(std::true_type{});
       else fast(std::false_type{});
       __syncthreads();   // staging read out; At / Bs free for the next tile's first unit
       ch = 0;
-      tile += NBLK;
+      tile = tile_of(++ck);
       continue;
     }
     // last (partial) tile / Cout below the padded width: bounds-checked read-out
@@ -499,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
     }
     __syncthreads();   // staging read out; At / Bs free for the next tile's first unit
     ch = 0;
-    tile += NBLK;
+    tile = tile_of(++ck);
   }
 }
 
