@@ -123,6 +123,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
   if (!op) return "?";
   switch (op->kind) {
     case FP_OP_CONV: {
+      if (fp_pws_eligible(*op)) return "pws_kernel";
       int nb, vec, pwd;
       fp_conv_variant(*op, &nb, &vec, &pwd);
       snprintf(buf, sizeof(buf), "conv_igemm_kernel<%d, %s, %s>", nb, vec ? "true" : "false", pwd ? "true" : "false");
@@ -146,6 +147,10 @@ const char* fp_op_kernel_name(const fp_op* op) {
         snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
     case FP_OP_DWPW:
+      if (fp_dwpw_persistent(*op)) {
+        snprintf(buf, sizeof(buf), "dwpw_persist_kernel<%d, %d>", (int)fp_round_up(op->Cout, 32) / 32, op->stride);
+        return buf;
+      }
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;

@@ -33,4 +33,7 @@ int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel, false: dwpw_kernel
+bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take the wave-private streaming kernel
+int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd);  // conv_igemm template arguments for an op

@@ -521,6 +521,21 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 
 }  // namespace
 
+static size_t dwpw_persist_lds(int NB, int G) {
+  const size_t ab = (size_t)TM * PLDT + (size_t)PKC * NB * 32, st = (size_t)TM * (2 * 32 + 4);
+  return 4 * ((ab > st ? ab : st) + (size_t)12 * G + TM);
+}
+
+// Persistent pipelined kernel over tiles of 32 2x2 patches, 2 resident workgroups per CU.  Cout = 128 at stride 2
+// (a 5x5 window + 4 accumulators per lane) spills and measured slower than the per-tile kernel: left to that one.
+bool fp_dwpw_persistent(const fp_op& op) {
+  const int NB = (int)fp_round_up(op.Cout, 32) / 32;
+  if (!(NB == 2 || (NB == 4 && op.stride == 1))) return false;
+  if (op.OH % 2 || op.OW % 2 || (op.stride == 2 && (op.H % 2 || op.W % 2))) return false;
+  if ((long)op.N * op.OH * op.OW < 1024L * TM) return false;
+  return dwpw_persist_lds(NB, op.Cin) <= 80 * 1024;
+}
+
 #ifdef FP_DWPW_STAMPS
 static unsigned long long* g_dwpw_stamps = nullptr;
 #endif
@@ -561,13 +576,9 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
 #endif
   const int NB = a.Npad / 32;
   const int P = (op.OW % 4 == 0) ? 4 : (op.OW % 2 == 0) ? 2 : 1;
-  // persistent pipelined kernel over tiles of 32 2x2 patches, 2 resident workgroups per CU.  Cout = 128 at stride 2
-  // (a 5x5 window + 4 accumulators per lane) spills and measured slower than the per-tile kernel: left to that one.
-  if ((NB == 2 || (NB == 4 && op.stride == 1)) && op.OH % 2 == 0 && op.OW % 2 == 0 &&
-      (op.stride == 1 || (op.H % 2 == 0 && op.W % 2 == 0)) && a.M >= 1024L * TM) {
-    const size_t ab = (size_t)TM * PLDT + (size_t)PKC * NB * 32, st = (size_t)TM * (2 * 32 + 4);
-    const size_t plds = 4 * ((ab > st ? ab : st) + (size_t)12 * a.G + TM);
-    if (plds <= 80 * 1024) {
+  if (fp_dwpw_persistent(op)) {
+    const size_t plds = dwpw_persist_lds(NB, a.G);
+    {
       DwPwArgs b = a;
       b.ntiles = (int)fp_ceil_div((long)op.N * (op.OH / 2) * (op.OW / 2), 32);
       int nblk = 512;
