@@ -123,7 +123,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
   if (!op) return "?";
   switch (op->kind) {
     case FP_OP_CONV: {
-      if (fp_pws_eligible(*op)) return "pws_kernel";
+      if (fp_pws_eligible(*op)) { snprintf(buf, sizeof(buf), "pws_kernel<%d>", op->Cin); return buf; }
       int nb, vec, pwd;
       fp_conv_variant(*op, &nb, &vec, &pwd);
       snprintf(buf, sizeof(buf), "conv_igemm_kernel<%d, %s, %s>", nb, vec ? "true" : "false", pwd ? "true" : "false");

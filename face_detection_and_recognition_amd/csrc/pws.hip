@@ -32,15 +32,17 @@ struct PwsArgs {
   long ntiles;   // 32-row tiles: M / 32
 };
 
-constexpr int KP = 64;          // K (= Kpad)
-constexpr int LDA = KP + 4;     // private A panel row stride (odd number of 16-B slots: conflict-free b128 reads)
+constexpr int KC = 64;          // K chunk held in the private panel (K = 64: the whole panel; K = 128: two chunks)
+constexpr int LDA = KC + 4;     // private A panel row stride (odd number of 16-B slots: conflict-free b128 reads)
 constexpr int BN = 128;         // N tile
 constexpr int NB = BN / 32;
 constexpr int WAVES = 8;
 constexpr int LDO = 64 + 4;     // output staging row stride (64 columns per pass)
 constexpr int PRIV = 32 * LDA;  // floats per wave (32*68; the staging tile [32][LDO] has the same size)
 
+template <int KP>
 __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
+  constexpr int NCH = KP / KC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                                  // [KP/4][BN][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,21 +89,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
 
   const long tstride = (long)nseq * WAVES;
   long t = (long)mseq * WAVES + wave;
-  f32x4 areg[8];
-  // panel of tile t: rows 32t .. 32t+31 are 8 KiB contiguous; lane -> row er + 4*j, 16-B column ec (16 lanes = 1 row)
+  f32x4 areg[NCH * 8];
+  // panel of tile t: rows 32t .. 32t+31 are one contiguous range; lane -> row er + 4*j, 16-B column ec of chunk c
+  // (16 lanes = 256 contiguous bytes of a row)
   auto load_panel = [&](long tt) {
     const float* src = p.in + (tt * 32 + er) * (long)p.in_ld + ec;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) areg[j] = *(const f32x4*)(src + (long)(4 * j) * p.in_ld);
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) areg[c * 8 + j] = *(const f32x4*)(src + (long)(4 * j) * p.in_ld + c * KC);
   };
   if (t < p.ntiles) load_panel(t);
 
   for (; t < p.ntiles; t += tstride) {
-    // A panel -> private LDS (the previous tile's read-out of this region is complete: same wave, in order)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *(f32x4*)&Ap[(er + 4 * j) * LDA + ec] = areg[j];
-    if (t + tstride < p.ntiles) load_panel(t + tstride);   // in flight during the MFMAs, the epilogue and its stores
-
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -109,13 +109,21 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
     const float* arow = &Ap[lr * LDA + 4 * h];
 #pragma unroll
-    for (int kq = 0; kq < KP / 8; ++kq) {
-      const f32x4 a = *(const f32x4*)(arow + kq * 8);
+    for (int c = 0; c < NCH; ++c) {
+      // chunk c of the A panel -> private LDS (earlier reads of this region are complete: same wave, in order)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const f32x4 bv = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+      for (int j = 0; j < 8; ++j) *(f32x4*)&Ap[(er + 4 * j) * LDA + ec] = areg[c * 8 + j];
+      // next tile's panel: in flight during the (last chunk's) MFMAs, the epilogue and its stores
+      if (c == NCH - 1 && t + tstride < p.ntiles) load_panel(t + tstride);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc[nb], 0, 0, 0);
+      for (int kq = 0; kq < KC / 8; ++kq) {
+        const f32x4 a = *(const f32x4*)(arow + kq * 8);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const f32x4 bv = *(const f32x4*)&Bs[((c * (KC / 4) + kq * 2 + h) * BN + nb * 32 + lr) * 4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc[nb], 0, 0, 0);
+        }
       }
     }
 
@@ -148,13 +156,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
 
 }  // namespace
 
-// Host-side eligibility: pointwise, dense NHWC in/out, K = 64, Cout a multiple of 128, M a multiple of 32,
+// Host-side eligibility: pointwise, dense NHWC in/out, K = 64 or 128, Cout a multiple of 128, M a multiple of 32,
 // no residual, activation none / ReLU / PReLU.  Everything else stays with conv_igemm_kernel.
 bool fp_pws_eligible(const fp_op& op) {
   if (op.kind != FP_OP_CONV) return false;
   if (op.KH != 1 || op.KW != 1 || op.stride != 1 || op.pad_t || op.pad_l) return false;
   if (op.OH != op.H || op.OW != op.W || op.out_cmul != 1) return false;
-  if (op.Cin != KP || op.Cout % BN || op.Cout <= 0) return false;
+  if ((op.Cin != 64 && op.Cin != 128) || op.Cout % BN || op.Cout <= 0) return false;
   const long HW = (long)op.H * op.W, M = (long)op.N * HW;
   if (op.in_ns != HW * op.in_ld || op.out_ns != HW * op.out_ld) return false;   // row m at base + m*ld
   if (op.in_ld % 4 || op.in_off % 4 || op.out_ld % 4 || op.out_off % 4 || op.w_off % 4) return false;
@@ -179,10 +187,14 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
   a.act = op.act;
   a.ntiles_n = op.Cout / BN;
   a.ntiles = (long)op.N * op.H * op.W / 32;
-  const size_t lds = 4 * ((size_t)KP * BN + (size_t)WAVES * PRIV);   // 32 KiB + 8 x 8.5 KiB = 100 KiB: 1 workgroup/CU
+  // weights (32 / 64 KiB) + 8 x 8.5 KiB private panels = 100 / 132 KiB: 1 workgroup per CU
+  const size_t lds = 4 * ((size_t)op.Cin * BN + (size_t)WAVES * PRIV);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)pws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)pws_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(4 * ((size_t)64 * BN + (size_t)WAVES * PRIV))) != hipSuccess ||
+        hipFuncSetAttribute((const void*)pws_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(4 * ((size_t)128 * BN + (size_t)WAVES * PRIV))) != hipSuccess) {
       fp_set_hip_error(hipGetLastError());
       return FP_ERR_LAUNCH;
     }
@@ -192,7 +204,8 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
   int grid = 256;
   const int unit = 8 * a.ntiles_n;
   grid = grid / unit * unit;
-  hipLaunchKernelGGL(pws_kernel, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  if (op.Cin == 64) hipLaunchKernelGGL(pws_kernel<64>, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  else hipLaunchKernelGGL(pws_kernel<128>, dim3(grid), dim3(WAVES * 64), lds, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
