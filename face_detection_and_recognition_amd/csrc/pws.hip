@@ -36,11 +36,10 @@ constexpr int KC = 64;          // K chunk held in the private panel (K = 64: th
 constexpr int LDA = KC + 4;     // private A panel row stride (odd number of 16-B slots: conflict-free b128 reads)
 constexpr int BN = 128;         // N tile
 constexpr int NB = BN / 32;
-constexpr int WAVES = 8;
 constexpr int LDO = 64 + 4;     // output staging row stride (64 columns per pass)
 constexpr int PRIV = 32 * LDA;  // floats per wave (32*68; the staging tile [32][LDO] has the same size)
 
-template <int KP>
+template <int KP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
   constexpr int NCH = KP / KC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -59,15 +58,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
 
   // weights of this N tile -> LDS, once: all loads first, then the LDS writes
   {
-    f32x4 wv[KP * BN / 4 / (WAVES * 64)];            // 4 float4 per lane
+    constexpr int NW4 = KP * BN / 4, PER = (NW4 + WAVES * 64 - 1) / (WAVES * 64);
+    f32x4 wv[PER];
 #pragma unroll
-    for (int j = 0; j < KP * BN / 4 / (WAVES * 64); ++j) {
-      const int i = tid + WAVES * 64 * j;
+    for (int j = 0; j < PER; ++j) {
+      const int i = min(tid + WAVES * 64 * j, NW4 - 1);
       const int q = i / BN, col = i - q * BN;
       wv[j] = *(const f32x4*)(p.w + ((long)q * p.Npad + n0 + col) * 4);
     }
 #pragma unroll
-    for (int j = 0; j < KP * BN / 4 / (WAVES * 64); ++j) *(f32x4*)&Bs[(tid + WAVES * 64 * j) * 4] = wv[j];
+    for (int j = 0; j < PER; ++j)
+      if (tid + WAVES * 64 * j < NW4) *(f32x4*)&Bs[(tid + WAVES * 64 * j) * 4] = wv[j];
   }
   // per-column affine of the MFMA layout (column = lane & 31 of each 32-column block)
   float sc[NB], bi[NB];
@@ -169,7 +170,7 @@ bool fp_pws_eligible(const fp_op& op) {
   if (op.res_mode != FP_RES_NONE) return false;
   if (op.act != FP_ACT_NONE && op.act != FP_ACT_RELU && op.act != FP_ACT_PRELU) return false;
   if (op.act == FP_ACT_PRELU && (op.slope_off < 0 || op.slope_off % 4)) return false;
-  if (M % 32 || M < 32L * WAVES * 256) return false;   // whole 32-row tiles, and enough of them to fill the chip
+  if (M % 32 || M < 32L * 12 * 256) return false;   // whole 32-row tiles, and enough of them to fill the chip
   return true;
 }
 
@@ -187,14 +188,16 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
   a.act = op.act;
   a.ntiles_n = op.Cout / BN;
   a.ntiles = (long)op.N * op.H * op.W / 32;
-  // weights (32 / 64 KiB) + 8 x 8.5 KiB private panels = 100 / 132 KiB: 1 workgroup per CU
-  const size_t lds = 4 * ((size_t)op.Cin * BN + (size_t)WAVES * PRIV);
+  // K = 64: weights 32 KiB + 12 x 8.5 KiB private panels = 134 KiB, 12 waves (3 per SIMD, 167 VGPRs);
+  // K = 128: weights 64 KiB + 8 x 8.5 KiB = 132 KiB, 8 waves.  One workgroup per CU either way.
+  const int waves = op.Cin == 64 ? 12 : 8;
+  const size_t lds = 4 * ((size_t)op.Cin * BN + (size_t)waves * PRIV);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)pws_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(4 * ((size_t)64 * BN + (size_t)WAVES * PRIV))) != hipSuccess ||
-        hipFuncSetAttribute((const void*)pws_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(4 * ((size_t)128 * BN + (size_t)WAVES * PRIV))) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)pws_kernel<64, 12>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(4 * ((size_t)64 * BN + (size_t)12 * PRIV))) != hipSuccess ||
+        hipFuncSetAttribute((const void*)pws_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(4 * ((size_t)128 * BN + (size_t)8 * PRIV))) != hipSuccess) {
       fp_set_hip_error(hipGetLastError());
       return FP_ERR_LAUNCH;
     }
@@ -204,8 +207,8 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
   int grid = 256;
   const int unit = 8 * a.ntiles_n;
   grid = grid / unit * unit;
-  if (op.Cin == 64) hipLaunchKernelGGL(pws_kernel<64>, dim3(grid), dim3(WAVES * 64), lds, s, a);
-  else hipLaunchKernelGGL(pws_kernel<128>, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  if (op.Cin == 64) hipLaunchKernelGGL((pws_kernel<64, 12>), dim3(grid), dim3(12 * 64), lds, s, a);
+  else hipLaunchKernelGGL((pws_kernel<128, 8>), dim3(grid), dim3(8 * 64), lds, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }

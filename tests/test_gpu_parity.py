@@ -234,6 +234,41 @@ def test_mobilefacenet_fused_and_unfused_plans_agree(dev):
         assert rel_err(y, ref) < 1e-5, (cin, cout, groups, stride, hw)
 
 
+@pytest.mark.parametrize("cin,cout,groups,stride,hw,residual,n", [
+    (64, 64, 128, 1, 28, True, 176),     # dwpw_persist<2,1> + pws<64>, whole tiles
+    (64, 64, 128, 1, 28, True, 169),     # partial last patch tile; M % 32 != 0 -> conv_igemm for the expand conv
+    (64, 64, 128, 2, 56, False, 168),    # dwpw_persist<2,2>
+    (128, 128, 256, 1, 14, True, 672),   # dwpw_persist<4,1> + pws<128>
+])
+def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, stride, hw, residual, n):
+    """The persistent / streaming kernels (csrc/dwpw.hip dwpw_persist_kernel, csrc/pws.hip) only take over above
+    ~1e5 output pixels, more than the golden fixtures hold: Depth_Wise blocks at bench-like batch sizes against the
+    oracle (mobilefacenet_ref._depth_wise = torch fp32 on the CPU), incl. a ragged last tile."""
+    rng = np.random.default_rng(1000 + hw + n)
+    blk = Depth_Wise(cin, cout, residual=residual, kernel=(3, 3), stride=(stride, stride), padding=(1, 1), groups=groups)
+    sd = synth_state_dict(blk.state_dict(), 900 + groups + stride + hw)
+    blk.load_state_dict(sd)
+    x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, cin)
+    y = blk.emit(pb, inp.view())
+    plan = CompiledPlan(pb, dev)
+    names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+    assert any(k.startswith("dwpw_persist_kernel") for k in names), names
+    m_rows = n * hw * hw
+    assert any(k.startswith("pws_kernel") for k in names) == (m_rows % 32 == 0), names
+    t = plan.buf_tensor(inp, n)
+    t.zero_()
+    t[..., :cin].copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    got = plan.buf_tensor(y, n)[..., :cout].permute(0, 3, 1, 2).cpu().numpy()
+    ref = mobilefacenet_ref._depth_wise({k: torch.as_tensor(v) for k, v in sd.items()}, "", torch.from_numpy(x),
+                                        stride, residual).numpy()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-5
+
+
 def test_mobilefacenet_forward_vs_reference_golden(dev):
     g = golden("mobilefacenet_forward")
     net = MobileFaceNet(512)
