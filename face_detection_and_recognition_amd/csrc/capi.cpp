@@ -124,6 +124,10 @@ const char* fp_op_kernel_name(const fp_op* op) {
   switch (op->kind) {
     case FP_OP_CONV: {
       if (fp_pws_eligible(*op)) { snprintf(buf, sizeof(buf), "pws_kernel<%d>", op->Cin); return buf; }
+      if (fp_stem_eligible(*op)) {
+        snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
+        return buf;
+      }
       int nb, vec, pwd;
       fp_conv_variant(*op, &nb, &vec, &pwd);
       snprintf(buf, sizeof(buf), "conv_igemm_kernel<%d, %s, %s>", nb, vec ? "true" : "false", pwd ? "true" : "false");

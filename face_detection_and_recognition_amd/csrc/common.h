@@ -36,4 +36,6 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel, false: dwpw_kernel
 bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take the wave-private streaming kernel
 int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)
+int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd);  // conv_igemm template arguments for an op

@@ -1,0 +1,228 @@
+// stem.hip — first conv of the networks: KxK stride-2 conv on a 3(+1 pad)-channel image (gfx950).
+//
+// BlazeFace's stem (fde/modules/blazeface/blazeface.py:176-180: F.pad(1,2,1,2) + Conv2d(3, 24, 5, stride 2) + ReLU) and
+// Mobile-FaceNet's conv1 (fde/modules/mobile_facenet/mobile_facenet.py:116: Conv_block(3, 64, 3x3, stride 2, pad 1),
+// BN, PReLU) read a 4-float pixel (RGB + one zero channel).  As an implicit GEMM their A operand is pure gather: with
+// conv.hip every lane fetched its row's taps one 16-B pixel at a time (25 scattered loads per output pixel for the
+// 5x5), 1.4-2.2 TB/s algorithmic (profiles/r01).  A tap of 4 channels IS one pixel, and an MFMA A fragment of 4
+// consecutive k is one tap -- so here the input rows a tile needs are staged ONCE into LDS with coalesced loads
+// (zero-filled borders) and the fragments are ds_read_b128 straight out of that image:  no im2col, no gathers.
+//   tile      = 128 consecutive output pixels of ONE image (raster order; wave w owns pixels 32w..32w+31)
+//   LDS       = image rows [nrows][Wp] float4 | packed weights [Kpad/4][Npad][4] | output tile [128][Cout]
+//   pipeline  = persistent workgroups; the next tile's image rows are loaded into registers (<= 6 float4 per lane)
+//               before the current tile's MFMAs and written to LDS after its epilogue
+//   epilogue  = acc*scale+bias, branch-free none/ReLU/PReLU, through LDS, then the tile's rows leave as ONE
+//               contiguous run (dense NHWC output: 128 x Cout floats)
+// k order and the packed weights are conv.hip's (k = tap*4 + c, zero rows up to Kpad): same products in the same
+// order, identical results.
+#include "common.h"
+
+namespace {
+
+struct StemArgs {
+  const float* in;
+  float* out;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* slope;
+  int H, W, OH, OW, OHW, Cout, Npad, Kpad, act, pad_t, pad_l, Wp, rows_max, tiles_per_img, ntiles;
+  long in_ns;
+};
+
+constexpr int TMS = 128;
+constexpr int PF = 6;   // staged float4s per lane and tile (rows_max * Wp <= PF * 256, checked on the host)
+
+template <int KS, int NB>
+__global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int NTAP = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Img = smem;                                   // [rows_max][Wp][4]
+  float* Bs = Img + p.rows_max * p.Wp * 4;             // [Kpad/4][BN][4]
+  float* Ot = Bs + p.Kpad * BN;                        // [128][Cout]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+  // weights -> LDS once (the packed blob is [Kpad/4][Npad][4] with Npad == BN)
+  for (int i = tid; i < (p.Kpad >> 2) * BN; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.w + (long)i * 4);
+  float sc[NB], bi[NB], sl[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = nb * 32 + lr;
+    const int nn = n < p.Cout ? n : 0;
+    sc[nb] = p.scale ? p.scale[nn] : 1.f;
+    bi[nb] = p.bias ? p.bias[nn] : 0.f;
+    sl[nb] = p.act == FP_ACT_PRELU ? p.slope[nn] : (p.act == FP_ACT_RELU ? 0.f : 1.f);
+  }
+
+  const int G = gridDim.x;
+  int pos;
+  {
+    const int b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
+    pos = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+
+  // staging of a tile's image rows: lane -> float4 slots tid + 256*j of the [nrows][Wp] image
+  f32x4 pre[PF];
+  unsigned premask = 0;
+  auto issue_stage = [&](int tile) {
+    const int img = tile / p.tiles_per_img, tin = tile - img * p.tiles_per_img;
+    const int m_lo = tin * TMS, m_hi = min(m_lo + TMS, p.OHW) - 1;
+    const int oy_lo = m_lo / p.OW, oy_hi = m_hi / p.OW;
+    const int iy_lo = oy_lo * 2 - p.pad_t, nslots = ((oy_hi - oy_lo) * 2 + KS) * p.Wp;
+    const float* ib = p.in + (long)img * p.in_ns;
+    premask = 0;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i / p.Wp, xp = i - row * p.Wp;
+      const int iy = iy_lo + row, ix = xp - p.pad_l;
+      const bool ok = i < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      pre[j] = *(const f32x4*)(ib + ((long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)) * 4);
+      if (ok) premask |= 1u << j;
+    }
+  };
+
+  auto write_stage = [&]() {   // staged registers -> LDS image; zero padding applied here, when they are consumed
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + 256 * j;
+      if (i < p.rows_max * p.Wp) *(f32x4*)&Img[i * 4] = ((premask >> j) & 1u) ? pre[j] : z4;
+    }
+  };
+
+  int tile = pos;
+  if (tile < p.ntiles) {
+    issue_stage(tile);
+    write_stage();
+  }
+  __syncthreads();   // weights and the first image staged
+  for (int k = 0; tile < p.ntiles; ++k) {
+    const int next = (k + 1) * G + pos;
+    if (next < p.ntiles) issue_stage(next);   // in flight during the MFMAs and the epilogue
+
+    const int img = tile / p.tiles_per_img, tin = tile - img * p.tiles_per_img;
+    const int m_lo = tin * TMS;
+    const int nvalid = min(TMS, p.OHW - m_lo);
+    // this lane's output pixel (rows past the image end recompute the last pixel; they are not stored)
+    const int m = min(m_lo + wave * 32 + lr, p.OHW - 1);
+    const int oy = m / p.OW, ox = m - oy * p.OW;
+    const float* base = Img + (((oy - m_lo / p.OW) * 2) * p.Wp + ox * 2) * 4;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    for (int kq = 0; kq < (p.Kpad >> 3); ++kq) {
+      // fragment of 4 consecutive k = tap 2*kq + h (taps past KS*KS meet zero weights: any finite pixel will do)
+      int t = 2 * kq + h;
+      t = t < NTAP ? t : 0;
+      const int ky = t / KS, kx = t - ky * KS;
+      const f32x4 a = *(const f32x4*)(base + (ky * p.Wp + kx) * 4);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const f32x4 bv = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc[nb], 0, 0, 0);
+      }
+    }
+    // epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = nb * 32 + lr;
+      if (n < p.Cout) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const float x = acc[nb][reg] * sc[nb] + bi[nb];
+          Ot[row * p.Cout + n] = x > 0.f ? x : __builtin_fmaf(x, sl[nb], 0.0f);
+        }
+      }
+    }
+    __syncthreads();   // Ot complete; every wave is done reading Img
+    // next image -> LDS BEFORE this tile's stores are issued: the wait for its loads (issued a whole MFMA phase ago)
+    // would otherwise also wait for those stores (vmcnt counts both)
+    if (next < p.ntiles) write_stage();
+    {
+      float* ob = p.out + ((long)img * p.OHW + m_lo) * p.Cout;
+      const int n4 = nvalid * p.Cout / 4;
+      for (int i = tid; i < n4; i += 256) *(f32x4*)(ob + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+    }
+    __syncthreads();   // next image visible; Ot free
+    tile = next;
+  }
+}
+
+size_t stem_lds_bytes(int rows_max, int Wp, int Kpad, int Npad, int Cout) {
+  return 4 * ((size_t)rows_max * Wp * 4 + (size_t)Kpad * Npad + (size_t)TMS * Cout);
+}
+
+}  // namespace
+
+// geometry shared by the eligibility test and the launcher
+static void stem_geometry(const fp_op& op, int* Wp, int* rows_max) {
+  const int pad_r = (op.OW - 1) * 2 - op.pad_l + op.KW - op.W;   // columns read right of the image
+  *Wp = op.pad_l + op.W + (pad_r > 0 ? pad_r : 0);
+  const int OHW = op.OH * op.OW;
+  int rows_touched = 1;                                          // output rows a tile (128-pixel run) can touch
+  for (int m_lo = 0; m_lo < OHW; m_lo += TMS) {
+    const int m_hi = (m_lo + TMS < OHW ? m_lo + TMS : OHW) - 1;
+    const int r = m_hi / op.OW - m_lo / op.OW + 1;
+    if (r > rows_touched) rows_touched = r;
+  }
+  *rows_max = (rows_touched - 1) * 2 + op.KH;
+}
+
+// KxK (3 or 5) stride-2 conv on a dense 4-float-pixel image into a dense NHWC tensor, Cout <= 64, no residual,
+// activation none / ReLU / PReLU.  Everything else stays with conv_igemm_kernel.
+bool fp_stem_eligible(const fp_op& op) {
+  if (op.kind != FP_OP_CONV || op.KH != op.KW || (op.KH != 3 && op.KH != 5) || op.stride != 2) return false;
+  if (op.Cin != 4 || op.in_ld != 4 || op.in_ns != (int64_t)op.H * op.W * 4 || op.in_off % 4) return false;
+  if (op.out_cmul != 1 || op.out_ld != op.Cout || op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return false;
+  if (op.Cout % 4 || op.Cout <= 0 || op.Cout > 64 || op.out_off % 4 || op.w_off % 4) return false;
+  if (op.res_mode != FP_RES_NONE) return false;
+  if (op.act != FP_ACT_NONE && op.act != FP_ACT_RELU && op.act != FP_ACT_PRELU) return false;
+  if (op.act == FP_ACT_PRELU && op.slope_off < 0) return false;
+  if (op.pad_t < 0 || op.pad_l < 0 || op.pad_t >= op.KH || op.pad_l >= op.KW) return false;
+  if (op.OH <= 0 || op.OW <= 0 || (op.OH - 1) * 2 - op.pad_t >= op.H || (op.OW - 1) * 2 - op.pad_l >= op.W) return false;
+  if ((long)op.N * op.OH * op.OW < 1024L * TMS) return false;     // small batches: one tile per workgroup is fine
+  int Wp, rows_max;
+  stem_geometry(op, &Wp, &rows_max);
+  if ((long)rows_max * Wp > PF * 256) return false;
+  const int Kpad = (int)fp_round_up(op.KH * op.KW * 4, 8), Npad = (int)fp_round_up(op.Cout, 32);
+  return stem_lds_bytes(rows_max, Wp, Kpad, Npad, op.Cout) <= 64 * 1024;
+}
+
+int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  StemArgs a;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.w = weights + op.w_off;
+  a.scale = op.scale_off >= 0 ? weights + op.scale_off : nullptr;
+  a.bias = op.bias_off >= 0 ? weights + op.bias_off : nullptr;
+  a.slope = op.slope_off >= 0 ? weights + op.slope_off : nullptr;
+  a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.OHW = op.OH * op.OW; a.Cout = op.Cout;
+  a.Kpad = (int)fp_round_up(op.KH * op.KW * 4, 8);
+  a.Npad = (int)fp_round_up(op.Cout, 32);
+  a.act = op.act; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+  stem_geometry(op, &a.Wp, &a.rows_max);
+  a.tiles_per_img = fp_ceil_div(a.OHW, TMS);
+  a.ntiles = op.N * a.tiles_per_img;
+  a.in_ns = op.in_ns;
+  const size_t lds = stem_lds_bytes(a.rows_max, a.Wp, a.Kpad, a.Npad, op.Cout);
+  int per_cu = (int)(160 * 1024 / lds);   // resident workgroups per CU by LDS (registers allow 3)
+  per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+  int grid = 256 * per_cu;
+  if (grid > a.ntiles) grid = a.ntiles;
+  const int NB = a.Npad / 32;
+  if (op.KH == 3 && NB == 1) hipLaunchKernelGGL((stem_conv_kernel<3, 1>), dim3(grid), dim3(256), lds, s, a);
+  else if (op.KH == 3 && NB == 2) hipLaunchKernelGGL((stem_conv_kernel<3, 2>), dim3(grid), dim3(256), lds, s, a);
+  else if (op.KH == 5 && NB == 1) hipLaunchKernelGGL((stem_conv_kernel<5, 1>), dim3(grid), dim3(256), lds, s, a);
+  else if (op.KH == 5 && NB == 2) hipLaunchKernelGGL((stem_conv_kernel<5, 2>), dim3(grid), dim3(256), lds, s, a);
+  else return FP_ERR_UNSUPPORTED;
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}

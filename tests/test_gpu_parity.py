@@ -269,6 +269,43 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
     assert rel_err(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("ks,cout,hw,n,act", [(5, 24, 256, 8, "relu"), (3, 64, 112, 48, "prelu"), (3, 24, 90, 70, "none")])
+def test_stem_conv_kernel_vs_torch(dev, ks, cout, hw, n, act):
+    """csrc/stem.hip (KxK stride-2 conv on the 4-float-pixel image, LDS-staged window) against torch's fp32 conv2d on
+    the CPU: BlazeFace's 5x5 stem, Mobile-FaceNet's 3x3 stem (ragged last tile: 3136 = 24.5 x 128), and an odd size."""
+    rng = np.random.default_rng(ks * 100 + hw)
+    x = rng.normal(0, 1, (n, 3, hw, hw)).astype(np.float32)
+    w = rng.normal(0, 0.2, (cout, 3, ks, ks)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    bias = rng.normal(0, 0.3, cout).astype(np.float32)
+    slope = rng.uniform(0.05, 0.4, cout).astype(np.float32)
+    oh = (hw + 2 - ks) // 2 + 1 if ks == 3 else (hw + 3 - ks) // 2 + 1     # pad 1 / F.pad(1, 2, 1, 2)
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, 3)
+    out = pb.new_buf(oh, oh, cout)
+    pb.conv(inp.view(), w, out.view(), stride=2, pad=(1, 1), scale=scale, bias=bias,
+            slope=slope if act == "prelu" else None,
+            act={"relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "none": L.ACT_NONE}[act])
+    plan = CompiledPlan(pb, dev)
+    assert plan.kernel_name(0).startswith("stem_conv_kernel"), plan.kernel_name(0)
+    t = plan.buf_tensor(inp, n)
+    t.zero_()
+    t[..., :3].copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    got = plan.buf_tensor(out, n)[..., :cout].permute(0, 3, 1, 2).cpu().numpy()
+    xt = torch.from_numpy(x)
+    xt = torch.nn.functional.pad(xt, (1, 2, 1, 2)) if ks == 5 else torch.nn.functional.pad(xt, (1, 1, 1, 1))
+    ref = torch.nn.functional.conv2d(xt, torch.from_numpy(w), stride=2)[:, :, :oh, :oh]
+    ref = ref * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(bias).view(1, -1, 1, 1)
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "prelu":
+        ref = torch.where(ref > 0, ref, ref * torch.from_numpy(slope).view(1, -1, 1, 1))
+    assert got.shape == tuple(ref.shape)
+    assert rel_err(got, ref.numpy()) < 1e-5
+
+
 def test_mobilefacenet_forward_vs_reference_golden(dev):
     g = golden("mobilefacenet_forward")
     net = MobileFaceNet(512)
