@@ -442,18 +442,19 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
       constexpr int SUBS = 8 / EB, NG = PASSES * SUBS;
       auto fast = [&](auto res_c) {
         constexpr bool RES = decltype(res_c)::value;
-        const int row0 = tid >> 4, cc = (tid & 15) * 4;   // 16 float4s per 64-column row; rows row0 + 16*j
+        // wave-private: a wave stages its own 32 rows and reads the same rows back as 16-B pieces (LDS is in order
+        // within a wave), so the passes need no workgroup barrier and the four waves drift apart
+        const int row0 = wave * 32 + (lane >> 4), cc = (lane & 15) * 4;   // rows row0 + 4*j, 16 float4s per 64-col row
         f32x4 rr[EB], v[EB];
-        auto load_res = [&](int grp) {   // group = (pass, sub): rows row0 + 16*(sub*EB + j), columns pass*64 + cc
+        auto load_res = [&](int grp) {   // group = (pass, sub): rows row0 + 4*(sub*EB + j), columns pass*64 + cc
           const int pass = grp / SUBS, sub = grp % SUBS;
 #pragma unroll
           for (int j = 0; j < EB; ++j)
-            rr[j] = *(const f32x4*)(p.res + (long)Mrow[row0 + 16 * (sub * EB + j)] * p.res_ld + pass * PW * 32 + cc);
+            rr[j] = *(const f32x4*)(p.res + (long)Mrow[row0 + 4 * (sub * EB + j)] * p.res_ld + pass * PW * 32 + cc);
         };
         if (RES) load_res(0);
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
-          if (pass) __syncthreads();
 #pragma unroll
           for (int q = 0; q < PW; ++q) {
             const int nb = pass * PW + q;
@@ -464,19 +465,18 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
               acc[nb][reg] = 0.f;
             }
           }
-          __syncthreads();
 #pragma unroll
           for (int sub = 0; sub < SUBS; ++sub) {
             const int grp = pass * SUBS + sub;
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
-              v[j] = *(const f32x4*)&smem[(row0 + 16 * (sub * EB + j)) * LDO + cc];
+              v[j] = *(const f32x4*)&smem[(row0 + 4 * (sub * EB + j)) * LDO + cc];
               if (RES) v[j] += rr[j];
             }
             if (RES && grp + 1 < NG) load_res(grp + 1);   // before this group's stores (see above)
 #pragma unroll
             for (int j = 0; j < EB; ++j)
-              *(f32x4*)(p.out + (long)Mrow[row0 + 16 * (sub * EB + j)] * p.out_ld + pass * PW * 32 + cc) = v[j];
+              *(f32x4*)(p.out + (long)Mrow[row0 + 4 * (sub * EB + j)] * p.out_ld + pass * PW * 32 + cc) = v[j];
           }
         }
       };
