@@ -82,6 +82,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     const int64_t pw = ((op.Cin + 7) / 8 * 8) * (int64_t)((op.Cout + 31) / 32 * 32) + 2 * (int64_t)((op.Cout + 3) / 4 * 4);
     if (!span_ok(op.slope_off, pw, weight_floats)) return FP_ERR_BOUNDS;
     if (op.act != FP_ACT_NONE && op.act != FP_ACT_PRELU) return FP_ERR_INVALID_ARG;
+    // bias_off: optional [Cout4] PReLU slopes of the projection output
+    if (op.bias_off >= 0 && !span_ok(op.bias_off, (op.Cout + 3) / 4 * 4, weight_floats)) return FP_ERR_BOUNDS;
+    if (op.bias_off >= 0 && op.res_mode != FP_RES_NONE) return FP_ERR_UNSUPPORTED;
   }
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV) {
     if (op.scale_off >= 0 && !span_ok(op.scale_off, Cout, weight_floats)) return FP_ERR_BOUNDS;

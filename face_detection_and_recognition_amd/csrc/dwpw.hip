@@ -25,6 +25,7 @@ struct DwPwArgs {
   const float* res;
   const float* dwp;  // [9*G dw weights][G scale][G bias][G slope]
   const float* pwp;  // [Kpad*Npad packed 1x1 weights][Cout scale][Cout bias]
+  const float* oslope;  // optional [Cout4] PReLU slopes applied to the projection output (before the residual add)
   int N, H, W, OH, OW, G, Cout, stride;
   int in_ld, out_ld, res_ld;
   long in_ns;
@@ -204,6 +205,11 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
       const int n = ncol0 + c4 * 4;
       if (m >= p.M || n >= p.Cout) continue;
       f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
+      if (p.oslope) {
+        const f32x4 os = *(const f32x4*)(p.oslope + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * os[e];
+      }
       if (p.has_res) v += *(const f32x4*)(p.res + m * p.res_ld + n);
       *(f32x4*)(p.out + m * p.out_ld + n) = v;
     }
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
   float* Bs = smem + TM * PLDT;     // [PKC/4][BN][4]       projection weights of the current unit
   float* Ws = smem + WS0;           // [12][G]              taps 0..8, scale, bias, slope (ones without PReLU)
   int* Mrow = (int*)(Ws + 12 * p.G);  // [TM]               output pixel index of each tile row (-1: past the end)
+  float* Osl = (float*)(Mrow + TM);   // [BN]               output PReLU slopes (ones without one)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
@@ -253,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
     if (row < 11 || p.has_slope) v = *(const f32x4*)(p.dwp + (long)i * 4);
     *(f32x4*)&Ws[i * 4] = v;
   }
+
+  if (tid < BN) Osl[tid] = (p.oslope && tid < p.Cout) ? p.oslope[tid] : 1.f;
 
   // XCD-aware position of this block inside a window of gridDim.x tiles (bijective for any grid size)
   const int NBLK = gridDim.x;
@@ -440,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
       constexpr int PASSES = NB / PW;
       constexpr int EB = NB == 4 ? 4 : 8;          // float4s per lane and group (register budget: 2 x EB float4s live)
       constexpr int SUBS = 8 / EB, NG = PASSES * SUBS;
-      auto fast = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
+      auto fast = [&](auto res_c, auto oact_c) {
+        constexpr bool RES = decltype(res_c)::value, OACT = decltype(oact_c)::value;
         // wave-private: a wave stages its own 32 rows and reads the same rows back as 16-B pieces (LDS is in order
         // within a wave), so the passes need no workgroup barrier and the four waves drift apart
         const int row0 = wave * 32 + (lane >> 4), cc = (lane & 15) * 4;   // rows row0 + 4*j, 16 float4s per 64-col row
@@ -465,12 +474,18 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
               acc[nb][reg] = 0.f;
             }
           }
+          f32x4 osl = {1.f, 1.f, 1.f, 1.f};
+          if (OACT) osl = *(const f32x4*)&Osl[pass * PW * 32 + cc];
 #pragma unroll
           for (int sub = 0; sub < SUBS; ++sub) {
             const int grp = pass * SUBS + sub;
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
               v[j] = *(const f32x4*)&smem[(row0 + 4 * (sub * EB + j)) * LDO + cc];
+              if (OACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * osl[e];
+              }
               if (RES) v[j] += rr[j];
             }
             if (RES && grp + 1 < NG) load_res(grp + 1);   // before this group's stores (see above)
@@ -480,8 +495,9 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
           }
         }
       };
-      if (p.has_res) fast(std::true_type{});
-      else fast(std::false_type{});
+      if (p.oslope) fast(std::false_type{}, std::true_type{});   // the planner never combines the two
+      else if (p.has_res) fast(std::true_type{}, std::false_type{});
+      else fast(std::false_type{}, std::false_type{});
       __syncthreads();   // staging read out; At / Bs free for the next tile's first unit
       ch = 0;
       tile = tile_of(++ck);
@@ -509,6 +525,11 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
         const int m = Mrow[row];
         if (m < 0 || n >= p.Cout) continue;
         f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
+        if (p.oslope) {
+          const f32x4 os = *(const f32x4*)&Osl[n];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * os[e];
+        }
         if (p.has_res) v += *(const f32x4*)(p.res + (long)m * p.res_ld + n);
         *(f32x4*)(p.out + (long)m * p.out_ld + n) = v;
       }
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 
 static size_t dwpw_persist_lds(int NB, int G) {
   const size_t ab = (size_t)TM * PLDT + (size_t)PKC * NB * 32, st = (size_t)TM * (2 * 32 + 4);
-  return 4 * ((ab > st ? ab : st) + (size_t)12 * G + TM);
+  return 4 * ((ab > st ? ab : st) + (size_t)12 * G + TM + (size_t)NB * 32);
 }
 
 // Persistent pipelined kernel over tiles of 32 2x2 patches, 2 resident workgroups per CU.  Cout = 128 at stride 2
@@ -562,6 +583,8 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
   a.res = has_res ? arena + op.res_off : nullptr;
   a.dwp = weights + op.w_off;
   a.pwp = weights + op.slope_off;
+  a.oslope = op.bias_off >= 0 ? weights + op.bias_off : nullptr;   // output PReLU (never together with a residual)
+  if (a.oslope && (has_res || op.bias_off % 4)) return FP_ERR_UNSUPPORTED;
   a.N = op.N; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.G = op.Cin; a.Cout = op.Cout; a.stride = op.stride;
   a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.res_ld = op.res_ld; a.in_ns = op.in_ns;
   a.Npad = (int)fp_round_up(op.Cout, 32);

@@ -85,8 +85,10 @@ class Depth_Wise(_NoCompute):
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
 
-    def emit(self, pb, x):
-        a = self.conv.emit(pb, x)
+    def emit(self, pb, x, expanded=None):
+        """expanded: the output of self.conv when the caller has already produced it (fused into the previous
+        depthwise Conv_block, see MobileFaceNet._emit); x is then only the residual source."""
+        a = expanded if expanded is not None else self.conv.emit(pb, x)
         dw, pj = self.conv_dw, self.project
         if (Depth_Wise.FUSE and dw.k == 3 and dw.p == 1 and dw.groups % 64 == 0 and pj.out_c % 4 == 0 and
                 pj.out_c <= 128):
@@ -166,8 +168,21 @@ class MobileFaceNet(nn.Module):
         pb = PlanBuilder(N)
         inp = pb.new_buf(H, W, 3)
         x = self.conv1.emit(pb, inp.view())
-        y = self.conv2_dw.emit(pb, x.view()); pb.free(x); x = y
-        y = self.conv_23.emit(pb, x.view()); pb.free(x); x = y
+        c2, c23 = self.conv2_dw, self.conv_23
+        if Depth_Wise.FUSE and c2.k == 3 and c2.s == 1 and c2.p == 1 and c2.groups % 64 == 0 and not c23.residual:
+            # conv2_dw (dw3x3 + BN + PReLU) -> conv_23.conv (1x1 + BN + PReLU) as ONE dw->pw kernel: the 64-channel
+            # 56x56 tensor between them (873 MB at N = 1088) never goes to HBM
+            ex = c23.conv
+            a = pb.new_buf(x.H, x.W, ex.out_c)
+            ds, db = _affine(c2.bn)
+            es, eb = _affine(ex.bn)
+            pb.dwpw(x.view(), npy(c2.conv.weight), ds, db, npy(c2.prelu.weight), npy(ex.conv.weight), es, eb,
+                    a.view(), 1, out_slope=npy(ex.prelu.weight))
+            pb.free(x)
+            x = c23.emit(pb, None, expanded=a)
+        else:
+            y = c2.emit(pb, x.view()); pb.free(x); x = y
+            y = c23.emit(pb, x.view()); pb.free(x); x = y
         x = self.conv_3.emit(pb, x)
         y = self.conv_34.emit(pb, x.view()); pb.free(x); x = y
         x = self.conv_4.emit(pb, x)

@@ -272,9 +272,11 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * cin + opix * cin + opix * cin + opix * cout))
         return out
 
-    def dwpw(self, x, dw_w, dw_scale, dw_bias, dw_slope, pw_w, pw_scale, pw_bias, out, stride, res=None):
+    def dwpw(self, x, dw_w, dw_scale, dw_bias, dw_slope, pw_w, pw_scale, pw_bias, out, stride, res=None,
+             out_slope=None):
         """Fused Depth_Wise tail (mobile_facenet.py:72-85): dw3x3 stride s (+BN affine, +PReLU) -> 1x1 (+BN affine)
-        [+ res].  x has G (multiple of 64) channels."""
+        [+ res], or -- with out_slope -- a depthwise Conv_block followed by a 1x1 Conv_block (BN + PReLU on both:
+        conv2_dw -> conv_23.conv, mobile_facenet.py:117-118,70).  x has G (multiple of 64) channels."""
         G = dw_w.shape[0]
         cout, cin = pw_w.shape[0], pw_w.shape[1]
         assert cin == G == x.C and G % 64 == 0 and out.cmul == 1 and out.coff == 0 and out.buf.ld == out.C
@@ -290,6 +292,9 @@ class PlanBuilder:
         c4 = round_up(out.C, 4)
         op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(pw_w, G, out.C), pad_vec(pw_scale, c4),
                                                        pad_vec(pw_bias, c4)]))
+        if out_slope is not None:
+            assert res is None
+            op.bias_off = self.add_weight(pad_vec(out_slope, c4))
         if res is not None:
             assert res.cmul == 1
             op.res_mode = L.RES_ADD_AFTER_ACT

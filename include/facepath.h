@@ -106,6 +106,8 @@ typedef struct fp_op {
  *   DWPW   : w_off     -> [9][G] depthwise taps, [G] scale, [G] bias, [G] PReLU slope   (12*G floats)
  *            slope_off -> packed 1x1 weights as for CONV (K = G), then [roundup(Cout,4)] scale, [roundup(Cout,4)] bias
  *            act = FP_ACT_PRELU if the depthwise has a PReLU; res_mode = FP_RES_ADD_AFTER_ACT adds res after the 1x1.
+ *            bias_off  -> optional [roundup(Cout,4)] PReLU slopes applied to the 1x1 output (a depthwise Conv_block
+ *            followed by a 1x1 Conv_block, mobile_facenet.py:117-118,70); not combined with a residual.
  *   BLAZEBLOCK : w_off -> [9][Cin] taps, scale_off -> [Cin] depthwise bias, slope_off -> packed 1x1, bias_off -> [Cout]
  */
 

@@ -306,6 +306,39 @@ def test_stem_conv_kernel_vs_torch(dev, ks, cout, hw, n, act):
     assert rel_err(got, ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("n,hw", [(48, 56), (2, 56), (3, 14)])
+def test_dwpw_with_output_prelu_vs_torch(dev, n, hw):
+    """FP_OP_DWPW with bias_off (output PReLU): depthwise Conv_block -> 1x1 Conv_block (conv2_dw -> conv_23.conv,
+    mobile_facenet.py:117-118,70) in one kernel, persistent (n = 48) and per-tile (small n) variants, vs torch fp32."""
+    rng = np.random.default_rng(77 + n)
+    G, cout = 64, 128
+    x = rng.normal(0, 1, (n, G, hw, hw)).astype(np.float32)
+    dw_w = rng.normal(0, 0.3, (G, 1, 3, 3)).astype(np.float32)
+    pw_w = rng.normal(0, 0.15, (cout, G, 1, 1)).astype(np.float32)
+    ds, db, dsl = (rng.uniform(0.5, 1.5, G).astype(np.float32), rng.normal(0, 0.2, G).astype(np.float32),
+                   rng.uniform(0.05, 0.5, G).astype(np.float32))
+    ps, pbi, psl = (rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.2, cout).astype(np.float32),
+                    rng.uniform(0.05, 0.5, cout).astype(np.float32))
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, G)
+    out = pb.new_buf(hw, hw, cout)
+    pb.dwpw(inp.view(), dw_w, ds, db, dsl, pw_w, ps, pbi, out.view(), 1, out_slope=psl)
+    plan = CompiledPlan(pb, dev)
+    assert plan.kernel_name(0).startswith("dwpw_persist_kernel") == (n * hw * hw >= 131072), plan.kernel_name(0)
+    t = plan.buf_tensor(inp, n)
+    t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    got = plan.buf_tensor(out, n).permute(0, 3, 1, 2).cpu().numpy()
+    F = torch.nn.functional
+    v = lambda a: torch.from_numpy(a).view(1, -1, 1, 1)
+    y = F.conv2d(torch.from_numpy(x), torch.from_numpy(dw_w), padding=1, groups=G) * v(ds) + v(db)
+    y = torch.where(y > 0, y, y * v(dsl))
+    y = F.conv2d(y, torch.from_numpy(pw_w)) * v(ps) + v(pbi)
+    y = torch.where(y > 0, y, y * v(psl))
+    assert rel_err(got, y.numpy()) < 1e-5
+
+
 def test_mobilefacenet_forward_vs_reference_golden(dev):
     g = golden("mobilefacenet_forward")
     net = MobileFaceNet(512)
