@@ -540,7 +540,45 @@ struct PoolArgs {
   long total;
 };
 
+// One lane = one output pixel x 4 channels.  All K*K taps are requested with clamped addresses before the first max
+// (a load behind an `if (inside)` branch is waited for before the next one is issued: K*K serial round trips), and
+// the row decode is 32-bit (total < 2^31 is checked on the host).
+template <int K>
 __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs p) {
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (unsigned)p.total) return;
+  const unsigned m = idx / (unsigned)p.C4, c4 = idx - m * (unsigned)p.C4;
+  const unsigned img = m / (unsigned)p.OHW, pix = m - img * (unsigned)p.OHW;
+  const int oy = (int)(pix / (unsigned)p.OW), ox = (int)(pix - (unsigned)oy * (unsigned)p.OW);
+  const float* ibase = p.in + (long)img * p.in_ns + c4 * 4;
+  const float ninf = -__builtin_huge_valf();
+  const f32x4 ninf4 = {ninf, ninf, ninf, ninf};
+  const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+  f32x4 x[K][K];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = iy0 + ky;
+    const float* rowp = ibase + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) x[ky][kx] = *(const f32x4*)(rowp + (long)min(max(ix0 + kx, 0), p.W - 1) * p.in_ld);
+  }
+  f32x4 acc = ninf4;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const bool vy = (unsigned)(iy0 + ky) < (unsigned)p.H;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const bool v = vy && (unsigned)(ix0 + kx) < (unsigned)p.W;
+      const f32x4 t = v ? x[ky][kx] : ninf4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], t[e]);
+    }
+  }
+  *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c4 * 4) = acc;
+}
+
+// Any other window size: the plain loop.
+__global__ __launch_bounds__(256) void maxpool_generic_kernel(PoolArgs p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= p.total) return;
   const int c4 = (int)(idx % p.C4);
@@ -768,7 +806,12 @@ int fp_launch_maxpool(const fp_op& op, float* arena, hipStream_t s) {
   PoolArgs a;
   int rc = fill_pool_args(op, arena, a);
   if (rc) return rc;
-  hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)fp_ceil_div(a.total, 256)), block(256);
+  const bool small = a.total < (1L << 31);
+  if (small && a.K == 2) hipLaunchKernelGGL(maxpool_kernel<2>, grid, block, 0, s, a);
+  else if (small && a.K == 3) hipLaunchKernelGGL(maxpool_kernel<3>, grid, block, 0, s, a);
+  else if (small && a.K == 5) hipLaunchKernelGGL(maxpool_kernel<5>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(maxpool_generic_kernel, grid, block, 0, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
