@@ -126,7 +126,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
   if (!op) return "?";
   switch (op->kind) {
     case FP_OP_CONV: {
-      if (fp_pws_eligible(*op)) { snprintf(buf, sizeof(buf), "pws_kernel<%d>", op->Cin); return buf; }
+      if (fp_pws_eligible(*op)) { snprintf(buf, sizeof(buf), "pws_kernel<%d, %d>", op->Cin, op->Cin == 64 ? 12 : 8); return buf; }
       if (fp_stem_eligible(*op)) {
         snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
         return buf;
