@@ -280,6 +280,19 @@ int fp_l2_mean_thres(const float* ref, int R, int D, float* out_mean, float* out
 int fp_l2_filter(const float* E, int64_t M, int D, const float* mean, const float* thres /*device [1]*/,
                  float* dist, uint8_t* keep, void* stream);
 
+/*
+ * Face-tracker matching for one frame (fde/face_extraction/extract_and_label_faces_from_dataset.py:101-121,
+ * Net.check_if_face_exists + Net.add_face; IoU = fde/modules/utils/image.py:124-143).  The F new faces are
+ * processed in order; each is compared with the known faces in insertion order and takes the FIRST one with
+ * (dist < normal_thres && iou > 0.1) || dist < harsh_thres, whose stored feature and box it then replaces; without
+ * a match it is appended (id = count + 1).  mode 0: dist = ||a - b||_2 (MOBILE_FACENET), mode 1: cosine distance.
+ * feats [cap][D] fp32, bboxes [cap][4] int32 (x, y, xw, yh), count [1] int32 are device state updated in place;
+ * ids[f] = 1-based face id (0 when the gallery is full), exists[f] = 1 if an existing face was matched.
+ */
+int fp_tracker_step(float* feats, int* bboxes, int* count, int cap, int D, const float* new_feats,
+                    const int* new_bboxes, int F, int mode, float normal_thres, float harsh_thres,
+                    int* ids, uint8_t* exists, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,3 +157,52 @@ def test_extract_faces_batched_matches_oracle_and_format(dev, tmp_path):
     assert total == sum(len(r.confs) for r in recs)
     assert a["media_id"] == "vid0" and a["label"] == 7 and len(a["frames_info"]) == 6
     assert a["feature"].shape == (X.MAX_N_FRAME_FROM_VID * X.MAX_N_FACES_PER_FRAME * 512,) and a["feature"].dtype == np.float32
+
+
+@pytest.mark.parametrize("tag,kind,batched", [("l2", "MOBILE_FACENET", True), ("cos", "FACE_REID_MNV3", True),
+                                               ("l2", "MOBILE_FACENET", False)])
+def test_face_tracker_matches_reference_golden(dev, tag, kind, batched):
+    """csrc/tracker.hip through FaceTracker (the reference's Net.check_if_face_exists / add_face rules,
+    extract_and_label_faces_from_dataset.py:101-121) against ids produced by the reference itself: one launch per
+    frame (batched) or the per-face API; final gallery state must equal the reference's list."""
+    from conftest import golden
+    from face_detection_and_recognition_amd.face_extraction.face_tracker import FaceTracker
+    g = golden("tracker")
+    feats, boxes, frame = g[tag + "_feats"], g[tag + "_boxes"], g[tag + "_frame"]
+    tr = FaceTracker(kind, feat_dim=feats.shape[1], device=dev, max_faces=32)
+    ids, exists = [], []
+    if batched:
+        for fr in np.unique(frame):
+            sel = np.nonzero(frame == fr)[0]
+            i, e = tr.track(torch.from_numpy(feats[sel]), torch.from_numpy(boxes[sel]))
+            ids += i.cpu().tolist()
+            exists += [bool(v) for v in e.cpu().tolist()]
+    else:
+        for f, b in zip(feats, boxes):
+            ok, fid, _, _ = tr.check_if_face_exists(f, tuple(int(v) for v in b))
+            if not ok:
+                fid = tr.get_num_unique_faces()
+                tr.add_face(f, b, 30, "M")
+            ids.append(fid)
+            exists.append(ok)
+    np.testing.assert_array_equal(np.asarray(ids, np.int32), g[tag + "_ids"])
+    np.testing.assert_array_equal(np.asarray(exists, bool), g[tag + "_exists"])
+    n = tr.get_num_unique_faces()
+    assert n == len(g[tag + "_final_boxes"])
+    np.testing.assert_array_equal(tr.feats[:n].cpu().numpy(), g[tag + "_final_feats"])
+    np.testing.assert_array_equal(tr.bboxes[:n].cpu().numpy(), g[tag + "_final_boxes"])
+
+
+def test_face_tracker_capacity_and_empty(dev):
+    from face_detection_and_recognition_amd.face_extraction.face_tracker import FaceTracker
+    tr = FaceTracker("MOBILE_FACENET", feat_dim=8, device=dev, max_faces=2)
+    i, e = tr.track(torch.zeros((0, 8)), torch.zeros((0, 4), dtype=torch.int32))
+    assert i.numel() == 0 and tr.get_num_unique_faces() == 0
+    f = torch.eye(8)[:3] * 10          # three mutually distant features, disjoint boxes
+    b = torch.tensor([[0, 0, 10, 10], [100, 100, 120, 120], [300, 300, 320, 320]], dtype=torch.int32)
+    i, e = tr.track(f, b)
+    assert i.cpu().tolist() == [1, 2, 0] and e.cpu().tolist() == [0, 0, 0]     # third face: gallery full -> id 0
+    tr.clear_faces()
+    assert tr.get_num_unique_faces() == 0
+    with pytest.raises(ValueError):
+        FaceTracker("MOBILE_FACENET", device=dev, use_bbox_iou_to_track_face=False)

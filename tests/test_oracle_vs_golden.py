@@ -131,3 +131,20 @@ def test_nms_restatement_consistent_with_reference_box_iou():
     for j in order:                                          # every dropped box is covered by a better kept one
         if j not in kept:
             assert any(iou[k, j] > 0.5 and scores[k] >= scores[j] for k in kept)
+
+
+def test_tracker_matching_vs_reference_golden():
+    """oracle/tracker_ref.py against the reference's own Net.check_if_face_exists / add_face and calculate_bbox_iou
+    (tests/golden/tracker.npz, tools/gen_golden.py gen_tracker)."""
+    from oracle import tracker_ref
+    g = golden("tracker")
+    iou = np.asarray([tracker_ref.calculate_bbox_iou(tuple(int(v) for v in a), tuple(int(v) for v in b))
+                      for a, b in zip(g["iou_b1"], g["iou_b2"])], np.float64)
+    np.testing.assert_array_equal(iou, g["iou"])
+    for tag, kind in (("l2", "MOBILE_FACENET"), ("cos", "FACE_REID_MNV3")):
+        tr = tracker_ref.FaceTrackerRef(kind)
+        ids, exists = tr.track(list(g[tag + "_feats"]), g[tag + "_boxes"])
+        np.testing.assert_array_equal(ids, g[tag + "_ids"])
+        np.testing.assert_array_equal(exists, g[tag + "_exists"])
+        np.testing.assert_array_equal(np.stack([e[1] for e in tr.faces]), g[tag + "_final_feats"])
+        np.testing.assert_array_equal(np.asarray([e[2] for e in tr.faces], np.int32), g[tag + "_final_boxes"])

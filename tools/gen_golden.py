@@ -200,10 +200,81 @@ def gen_yolo():
     save("yolo_box_iou", boxes=b1, iou=iou.numpy())
 
 
+def gen_tracker():
+    """Face-tracker matching: the reference's own Net.check_if_face_exists / Net.add_face
+    (fde/face_extraction/extract_and_label_faces_from_dataset.py:101-121) on seeded feature / box sequences.  The module
+    creates ./logs at import time, so it is imported with a scratch directory as cwd; the Net instance is made without
+    __init__ (which only loads onnx / openvino model files)."""
+    import contextlib
+    import importlib
+    import io
+    import tempfile
+    for name in ("openvino", "openvino.runtime", "openvino.inference_engine"):
+        if name not in sys.modules:
+            rh._stub(name, Core=object, IECore=object)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            mod = importlib.import_module("face_extraction.extract_and_label_faces_from_dataset")
+        finally:
+            os.chdir(cwd)
+    out = {}
+    for case, (kind, D, n_frames) in enumerate((("MOBILE_FACENET", 512, 24), ("FACE_REID_MNV3", 256, 24))):
+        rng = np.random.default_rng(500 + case)
+        net = object.__new__(mod.Net)
+        net.feat_net_type, net.normal_thres, net.harsh_thres, net.use_bbox_iou = kind, 1., 0.72, True
+        net.face_feat_bbox_age_gender_list, net.max_faceid = [], 0
+        # 5 identities wandering through the frames: unit features + noise (same identity: dist ~0.3-0.9, different: ~1.4),
+        # boxes drifting a few pixels per frame; distances within 1e-3 of a threshold are re-drawn
+        protos = rng.normal(0, 1, (5, D)).astype(np.float32)
+        protos /= np.linalg.norm(protos, axis=1, keepdims=True)
+        centres = rng.uniform(100, 900, (5, 2))
+        feats, boxes, frame_of, ids, exists = [], [], [], [], []
+        for fr in range(n_frames):
+            present = [k for k in range(5) if rng.uniform() < 0.6]
+            rng.shuffle(present)
+            for k in present:
+                centres[k] += rng.normal(0, 6, 2)
+                noise = rng.normal(0, 1, D).astype(np.float32)
+                noise /= np.linalg.norm(noise)
+                f = protos[k] + np.float32(rng.choice([0.3, 0.6, 0.85, 1.2])) * noise
+                if kind == "MOBILE_FACENET":
+                    f = (f / np.linalg.norm(f)).astype(np.float32)
+                else:
+                    f = (f * np.float32(rng.uniform(0.5, 3.0))).astype(np.float32)
+                half = rng.integers(30, 80)
+                b = (int(centres[k][0] - half), int(centres[k][1] - half), int(centres[k][0] + half), int(centres[k][1] + half))
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ok, fid, _, _ = net.check_if_face_exists(f, b)
+                    if not ok:
+                        fid = net.max_faceid + 1
+                        net.add_face(f, b, None, None)
+                feats.append(f); boxes.append(b); frame_of.append(fr); ids.append(fid); exists.append(ok)
+        tag = "l2" if kind == "MOBILE_FACENET" else "cos"
+        out[f"{tag}_feats"] = np.stack(feats)
+        out[f"{tag}_boxes"] = np.asarray(boxes, np.int32)
+        out[f"{tag}_frame"] = np.asarray(frame_of, np.int32)
+        out[f"{tag}_ids"] = np.asarray(ids, np.int32)
+        out[f"{tag}_exists"] = np.asarray(exists, bool)
+        out[f"{tag}_final_feats"] = np.stack([e[1] for e in net.face_feat_bbox_age_gender_list])
+        out[f"{tag}_final_boxes"] = np.asarray([e[2] for e in net.face_feat_bbox_age_gender_list], np.int32)
+    # IoU helper itself (fde/modules/utils/image.py:124-143)
+    from modules.utils.image import calculate_bbox_iou
+    rng = np.random.default_rng(9)
+    pairs = rng.integers(0, 200, (64, 2, 2))
+    b1 = np.concatenate([pairs[:, 0], pairs[:, 0] + rng.integers(1, 120, (64, 2))], 1)
+    b2 = np.concatenate([pairs[:, 1], pairs[:, 1] + rng.integers(1, 120, (64, 2))], 1)
+    out["iou_b1"], out["iou_b2"] = b1.astype(np.int32), b2.astype(np.int32)
+    out["iou"] = np.asarray([calculate_bbox_iou(tuple(int(v) for v in a), tuple(int(v) for v in b)) for a, b in zip(b1, b2)],
+                            np.float64)
+    save("tracker", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ns = rh.import_reference()
-    which = sys.argv[1:] or ["blazeface", "mobilefacenet", "utils", "similarity", "yolo"]
+    which = sys.argv[1:] or ["blazeface", "mobilefacenet", "utils", "similarity", "yolo", "tracker"]
     if "blazeface" in which:
         gen_blazeface(ns)
     if "mobilefacenet" in which:
@@ -214,3 +285,5 @@ if __name__ == "__main__":
         gen_similarity()
     if "yolo" in which:
         gen_yolo()
+    if "tracker" in which:
+        gen_tracker()
