@@ -106,3 +106,72 @@ extern "C" int fp_resize_normalize(const uint8_t* frames, int n_frames, int fram
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Face crops from a float CHW image: the tail of the Triton post-process model
+// (fde/modules/face_detection_trt_server/models/yolov5_face_postprocess/1/model.py:47-49,85-103):
+//   image (3, H, W) fp32 RGB in [0,1]  ->  *255, RGB->BGR  ->  crop [y:yh, x:xw]  ->  cv2.resize(.., (ow, oh)) on
+//   FLOAT data (INTER_LINEAR, half-pixel centres, float weights: horizontal pass then vertical)  ->  (v-127.5)/127.5
+//   ->  (3, oh, ow) planes.
+// One lane per output pixel, 3 channels.  cv2 is absent in the build container: "parity unpinned" like the u8 path;
+// oracle/triton_postprocess_ref.py restates the same arithmetic.
+namespace {
+
+struct CropF32Args {
+  const float* img;     // [3][H][W]
+  const int* boxes;     // [n][4] x, y, xw, yh (already clamped to the image, xw > x, yh > y)
+  float* out;           // [n][3][oh][ow]
+  int H, W, n, oh, ow;
+};
+
+__global__ __launch_bounds__(256) void crop_resize_f32_kernel(CropF32Args p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int per = p.oh * p.ow;
+  if (idx >= (long)p.n * per) return;
+  const int item = (int)(idx / per), pix = (int)(idx - (long)item * per);
+  const int dy = pix / p.ow, dx = pix - dy * p.ow;
+  const int x = p.boxes[item * 4 + 0], y = p.boxes[item * 4 + 1];
+  const int sw = p.boxes[item * 4 + 2] - x, sh = p.boxes[item * 4 + 3] - y;
+  // cv2 resizeGeneric_ / hresize / vresize for float: src coordinate (d + 0.5) * scale - 0.5 computed in double,
+  // floor, weight in float; taps outside the crop collapse onto the border pixel with weight 0
+  auto tap = [](int d, int dsize, int ssize, int& s0, int& s1, float& a1) {
+    const double scale = (double)ssize / dsize;
+    float fs = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(fs);
+    fs -= s;
+    if (s < 0) { s = 0; fs = 0.f; }
+    if (s >= ssize - 1) { s = ssize - 1; fs = 0.f; }
+    s0 = s;
+    s1 = min(s + 1, ssize - 1);
+    a1 = fs;
+  };
+  int sx0, sx1, sy0, sy1;
+  float ax, ay;
+  tap(dx, p.ow, sw, sx0, sx1, ax);
+  tap(dy, p.oh, sh, sy0, sy1, ay);
+  const float ax0 = 1.f - ax, ay0 = 1.f - ay;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* pl = p.img + (long)(2 - c) * p.H * p.W;   // BGR output channel c <- RGB plane 2-c
+    const float* r0 = pl + (long)(y + sy0) * p.W + x;
+    const float* r1 = pl + (long)(y + sy1) * p.W + x;
+    const float h0 = (r0[sx0] * 255.0f) * ax0 + (r0[sx1] * 255.0f) * ax;
+    const float h1 = (r1[sx0] * 255.0f) * ax0 + (r1[sx1] * 255.0f) * ax;
+    const float v = h0 * ay0 + h1 * ay;
+    p.out[((long)item * 3 + c) * per + pix] = (v - 127.5f) / 127.5f;
+  }
+}
+
+}  // namespace
+
+extern "C" int fp_crop_resize_f32(const float* image_chw, int H, int W, const int32_t* boxes, int n_boxes, float* out,
+                                  int out_h, int out_w, void* stream) {
+  if (!image_chw || H <= 0 || W <= 0 || n_boxes < 0 || out_h <= 0 || out_w <= 0) return FP_ERR_INVALID_ARG;
+  if (n_boxes == 0) return FP_OK;
+  if (!boxes || !out) return FP_ERR_INVALID_ARG;
+  CropF32Args a{image_chw, boxes, out, H, W, n_boxes, out_h, out_w};
+  const long total = (long)n_boxes * out_h * out_w;
+  hipLaunchKernelGGL(crop_resize_f32_kernel, dim3((unsigned)fp_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}

@@ -281,6 +281,16 @@ int fp_l2_filter(const float* E, int64_t M, int D, const float* mean, const floa
                  float* dist, uint8_t* keep, void* stream);
 
 /*
+ * Face crops from a float CHW image, the tail of the Triton python post-process model
+ * (fde/modules/face_detection_trt_server/models/yolov5_face_postprocess/1/model.py:47-49,85-103): image (3,H,W) fp32
+ * RGB in [0,1] -> *255, RGB->BGR -> crop [y:yh, x:xw] -> cv2.resize (float INTER_LINEAR) to (out_w, out_h) ->
+ * (v - 127.5)/127.5 -> out [n][3][out_h][out_w].  boxes [n][4] int32 (x, y, xw, yh) in DEVICE memory, already clamped
+ * to the image with xw > x and yh > y.  cv2 is absent offline: parity unpinned (restated in oracle/).
+ */
+int fp_crop_resize_f32(const float* image_chw, int H, int W, const int32_t* boxes, int n_boxes, float* out,
+                       int out_h, int out_w, void* stream);
+
+/*
  * Face-tracker matching for one frame (fde/face_extraction/extract_and_label_faces_from_dataset.py:101-121,
  * Net.check_if_face_exists + Net.add_face; IoU = fde/modules/utils/image.py:124-143).  The F new faces are
  * processed in order; each is compared with the known faces in insertion order and takes the FIRST one with

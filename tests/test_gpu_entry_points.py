@@ -206,3 +206,43 @@ def test_face_tracker_capacity_and_empty(dev):
     assert tr.get_num_unique_faces() == 0
     with pytest.raises(ValueError):
         FaceTracker("MOBILE_FACENET", device=dev, use_bbox_iou_to_track_face=False)
+
+
+def _triton_request(rng, n_faces, h=384, w=640):
+    """Three raw head tensors (1, 3, ny, nx, 16) with n_faces strong, well separated objects, and an RGB image."""
+    heads = []
+    for stride in (8, 16, 32):
+        t = rng.normal(0, 0.5, (1, 3, h // stride, w // stride, 16)).astype(np.float32)
+        t[..., 4] = -8.0                     # objectness logit: nothing fires ...
+        heads.append(t)
+    for k in range(n_faces):                 # ... except these cells of the stride-16 head (anchor 1: 43x55 px)
+        gy, gx = 4 + 5 * (k // 4), 4 + 9 * (k % 4)
+        heads[1][0, 1, gy, gx, 4] = 3.0 + 0.3 * k
+        heads[1][0, 1, gy, gx, 0:4] = rng.normal(0, 0.3, 4) + np.array([0, 0, 0.8, 0.8], np.float32)
+    img = rng.uniform(0, 1, (1, 3, h, w)).astype(np.float32)
+    return dict(stride_8_out=heads[0], stride_16_out=heads[1], stride_32_out=heads[2], images=img,
+                face_det_thres=np.asarray([0.7], np.float32), face_bbox_area_thres=np.asarray([0.1], np.float32))
+
+
+@pytest.mark.parametrize("n_faces", [5, 0])
+def test_triton_postprocess_contract_matches_oracle(dev, n_faces):
+    """modules/face_detection_trt_server/yolov5_face_postprocess.py (decode + w-NMS + float crop/resize kernels) against
+    oracle/triton_postprocess_ref.py, the restatement of the Triton python model (model.py:32-113): same boxes and
+    confidences, faces within 1e-4, and the zero-filled (1,3,112,112) / [[0,0,0,0]] / [[0.]] reply when nothing fires."""
+    from face_detection_and_recognition_amd.modules.face_detection_trt_server.yolov5_face_postprocess import \
+        YOLOv5FacePostprocess
+    from oracle import triton_postprocess_ref as ref
+    rng = np.random.default_rng(31 + n_faces)
+    req = _triton_request(rng, n_faces)
+    out = YOLOv5FacePostprocess(dev).execute([req])[0]
+    faces, boxes, confs = ref.execute(req["stride_8_out"], req["stride_16_out"], req["stride_32_out"], req["images"],
+                                      req["face_det_thres"][0], req["face_bbox_area_thres"][0])
+    assert out["face_detector_faces"].dtype == np.float32 and out["face_detector_bboxes"].dtype == np.int32
+    assert out["face_detector_bboxes"].shape == boxes.shape and out["face_detector_faces"].shape == faces.shape
+    np.testing.assert_array_equal(out["face_detector_bboxes"], boxes)
+    np.testing.assert_allclose(out["face_detector_confs"], confs, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["face_detector_faces"], faces, rtol=0, atol=1e-4)
+    if n_faces:
+        assert len(boxes) == n_faces and faces.shape[1:] == (3, 112, 112)
+    else:
+        assert faces.shape == (1, 3, 112, 112) and boxes.tolist() == [[0, 0, 0, 0]]

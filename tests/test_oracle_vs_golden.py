@@ -148,3 +148,18 @@ def test_tracker_matching_vs_reference_golden():
         np.testing.assert_array_equal(exists, g[tag + "_exists"])
         np.testing.assert_array_equal(np.stack([e[1] for e in tr.faces]), g[tag + "_final_feats"])
         np.testing.assert_array_equal(np.asarray([e[2] for e in tr.faces], np.int32), g[tag + "_final_boxes"])
+
+
+def test_triton_postprocess_oracle_decode_matches_reference_golden():
+    """oracle/triton_postprocess_ref._decode restates the server's utils.conv_strides_to_anchors, a verbatim twin of
+    onnx_utils.conv_strides_to_anchors whose output the yolo_decode_wnms golden holds."""
+    from oracle import triton_postprocess_ref as ref
+    g = golden("yolo_decode_wnms")
+    z = ref._decode([torch.from_numpy(g[f"head{i}"]) for i in range(3)])
+    np.testing.assert_array_equal(z.numpy(), g["z"])
+    # float bilinear resize: identity at equal size, constant images stay constant, corners map to corners
+    img = np.random.default_rng(0).uniform(0, 255, (9, 13, 3)).astype(np.float32)
+    np.testing.assert_array_equal(ref.resize_bilinear_f32(img, (13, 9)), img)
+    up = ref.resize_bilinear_f32(img, (39, 27))
+    assert up.shape == (27, 39, 3) and np.allclose(up[0, 0], img[0, 0]) and np.allclose(up[-1, -1], img[-1, -1])
+    assert np.allclose(ref.resize_bilinear_f32(np.full((5, 7, 3), 3.5, np.float32), (112, 112)), 3.5)
