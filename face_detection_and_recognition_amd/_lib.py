@@ -17,7 +17,7 @@ OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK
 # fp_act
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
 # fp_res_mode
-RES_NONE, RES_ADD_BEFORE_ACT, RES_ADD_AFTER_ACT, RES_POOL2_BEFORE_ACT = 0, 1, 2, 3
+RES_NONE, RES_ADD_BEFORE_ACT, RES_ADD_AFTER_ACT, RES_POOL2_BEFORE_ACT, RES_SHUFFLE2 = 0, 1, 2, 3, 4
 
 
 class FpOp(C.Structure):

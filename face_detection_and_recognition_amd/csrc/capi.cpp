@@ -45,8 +45,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   // input extent
   const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
   if (!span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
+  const int64_t out_ch = (op.kind == FP_OP_CONV && op.res_mode == FP_RES_SHUFFLE2) ? 2 * (int64_t)Cout : Cout;
   const int64_t out_ext =
-      (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (int64_t)(Cout - 1) * op.out_cmul + 1;
+      (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (out_ch - 1) * op.out_cmul + 1;
   if (!span_ok(op.out_off, out_ext, arena_floats)) return FP_ERR_BOUNDS;
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
@@ -94,7 +95,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.act < FP_ACT_NONE || op.act > FP_ACT_SILU) return FP_ERR_INVALID_ARG;
   }
   if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW) && op.res_mode != FP_RES_NONE) {
-    if (op.res_mode < FP_RES_NONE || op.res_mode > FP_RES_POOL2_BEFORE_ACT) return FP_ERR_INVALID_ARG;
+    if (op.res_mode < FP_RES_NONE || op.res_mode > FP_RES_SHUFFLE2) return FP_ERR_INVALID_ARG;
+    if (op.res_mode == FP_RES_SHUFFLE2 && (op.kind != FP_OP_CONV || op.out_cmul != 1 || op.out_ld < 2 * op.Cout))
+      return FP_ERR_INVALID_ARG;
     if (op.res_C <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
     int rh = OH, rw = OW;
     if (op.res_mode == FP_RES_POOL2_BEFORE_ACT) {

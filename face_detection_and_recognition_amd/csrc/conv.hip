@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
     const int act = p.act, res_mode = p.res_mode;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const bool silu = act == FP_ACT_SILU, has_res = res_mode != FP_RES_NONE, after = res_mode == FP_RES_ADD_AFTER_ACT;
+    const bool shuf = res_mode == FP_RES_SHUFFLE2;   // out[2n] = res[n], out[2n+1] = act(conv)[n]
     // Store loop of one pass.  Two rules shape it (both measured, tools/lab/README.md):
     //  * vmcnt counts loads AND stores of a wave in one queue, so a global load inside the store loop (slope,
     //    residual) makes every iteration wait for all earlier stores to be acknowledged (~1 us each under load).
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
           sl[j] = C4_FIXED ? sl_fixed : neg_slope(n);
           rr[j] = z4;
           if (PWD) {
-            ooff[j] = m * p.out_ld + n;
+            ooff[j] = m * p.out_ld + (shuf ? 2 * n : n);
             if (RES && ok[j] && n < p.res_C4) rr[j] = *(const f32x4*)(p.res + m * p.res_ld + n);
           } else {
             unsigned img = img_b, pix = pix_b + (unsigned)row;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
               img += qd;
               pix -= qd * uOHW;
             }
-            ooff[j] = (long)img * p.out_ns + (long)pix * p.out_ld + n;
+            ooff[j] = (long)img * p.out_ns + (long)pix * p.out_ld + (shuf ? 2 * n : n);
             if (RES && ok[j] && n < p.res_C4) {
               if (res_mode == FP_RES_POOL2_BEFORE_ACT) {
                 const unsigned oy = pix / (unsigned)p.OW, ox = pix - oy * (unsigned)p.OW;
@@ -298,14 +299,20 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float pre = (RES && !after) ? rr[j][e] : 0.f;
+            const float pre = (RES && !after && !shuf) ? rr[j][e] : 0.f;
             const float x = RES ? v[e] + pre : v[e];
             float y;
             if (SILU) y = x / (1.0f + expf(-x));
             else y = x > 0.f ? x : __builtin_fmaf(x, sl[j][e], 0.0f);
             o[e] = (RES && after) ? y + rr[j][e] : y;
           }
-          *(f32x4*)(p.out + ooff[j]) = o;
+          if (RES && shuf) {   // channel_shuffle(cat(res, y), 2) written as two 16-byte pieces
+            const f32x4 o0 = {rr[j][0], o[0], rr[j][1], o[1]}, o1 = {rr[j][2], o[2], rr[j][3], o[3]};
+            *(f32x4*)(p.out + ooff[j]) = o0;
+            *(f32x4*)(p.out + ooff[j] + 4) = o1;
+          } else {
+            *(f32x4*)(p.out + ooff[j]) = o;
+          }
         }
       }
     };
@@ -724,6 +731,7 @@ int fp_launch_conv(const fp_op& op, const float* weights, float* arena, hipStrea
   a.res_C4 = (int)fp_round_up(op.res_C, 4);
   const bool ve = conv_vec_epilogue(op);
   a.vec_epi = ve ? 1 : 0;
+  if (op.res_mode == FP_RES_SHUFFLE2 && (!ve || op.res_C < op.Cout)) return FP_ERR_UNSUPPORTED;
   int NB, vec_i, pwd_i;
   fp_conv_variant(op, &NB, &vec_i, &pwd_i);
   const bool vec = vec_i != 0, pwd = pwd_i != 0;

@@ -212,19 +212,22 @@ class ShuffleV2Block(_NoCompute):
         s = self.stride
         OH, OW = (x.H + 2 - 3) // s + 1, (x.W + 2 - 3) // s + 1
         out = pb.new_buf(OH, OW, self.oup)
-        even, odd = out.view(0, self.bf, cmul=2), out.view(1, self.bf, cmul=2)
+        # cat + channel_shuffle(2) is the last conv's epilogue (FP_RES_SHUFFLE2): out[2n] = other half, out[2n+1] = conv
         b2 = self.branch2
         if s == 1:
-            pb.copy(View(x.buf, x.coff, self.bf), even)                                  # x1 passthrough
+            first = View(x.buf, x.coff, self.bf)                                          # x1 passthrough
             x2 = View(x.buf, x.coff + self.bf, self.bf)
+            b1out = None
         else:
             b1 = self.branch1
             t = pb.new_buf(OH, OW, self.inp)
             sc, bi = _bn_sb(b1[1])
             pb.dwconv(x, npy(b1[0].weight), t.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
             sc, bi = _bn_sb(b1[3])
-            pb.conv(t.view(), npy(b1[2].weight), even, scale=sc, bias=bi, act=L.ACT_SILU)
+            b1out = pb.new_buf(OH, OW, self.bf)
+            pb.conv(t.view(), npy(b1[2].weight), b1out.view(), scale=sc, bias=bi, act=L.ACT_SILU)
             pb.free(t)
+            first = b1out.view()
             x2 = x
         t1 = pb.new_buf(x.H, x.W, self.bf)
         sc, bi = _bn_sb(b2[1])
@@ -234,7 +237,14 @@ class ShuffleV2Block(_NoCompute):
         pb.dwconv(t1.view(), npy(b2[3].weight), t2.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
         pb.free(t1)
         sc, bi = _bn_sb(b2[6])
-        pb.conv(t2.view(), npy(b2[5].weight), odd, scale=sc, bias=bi, act=L.ACT_SILU)
+        if self.bf % 4 == 0:
+            pb.conv(t2.view(), npy(b2[5].weight), out.view(0, self.bf), scale=sc, bias=bi, act=L.ACT_SILU,
+                    res=first, res_mode=L.RES_SHUFFLE2)
+        else:   # odd widths: scalar interleaved writes
+            pb.copy(first, out.view(0, self.bf, cmul=2))
+            pb.conv(t2.view(), npy(b2[5].weight), out.view(1, self.bf, cmul=2), scale=sc, bias=bi, act=L.ACT_SILU)
+        if b1out is not None:
+            pb.free(b1out)
         pb.free(t2)
         return out.view()
 

@@ -215,6 +215,8 @@ class PlanBuilder:
             op.bias_off = self.add_weight(pad_vec(bias, out.C, 0.0))
         if slope is not None:
             op.slope_off = self.add_weight(pad_vec(slope, out.C, 0.0))
+        if res_mode == L.RES_SHUFFLE2:   # out is the dense view of the conv's own Cout channels; 2*Cout are written
+            assert out.cmul == 1 and out.coff + 2 * out.C <= out.buf.ld and res is not None and res.C >= out.C
         if res_mode != L.RES_NONE:
             assert res is not None and res.cmul == 1
             op.res_ld = res.buf.ld

@@ -65,7 +65,10 @@ enum fp_res_mode {
   FP_RES_NONE = 0,
   FP_RES_ADD_BEFORE_ACT = 1, /* act(conv + res): BlazeBlock (blazeface.py:47) */
   FP_RES_ADD_AFTER_ACT = 2,  /* res + act(conv): Depth_Wise residual (mobile_facenet.py:84-85), Bottleneck (common.py:87) */
-  FP_RES_POOL2_BEFORE_ACT = 3 /* res = maxpool2x2(input map) zero-padded on channels (blazeface.py:38-45) */
+  FP_RES_POOL2_BEFORE_ACT = 3, /* res = maxpool2x2(input map) zero-padded on channels (blazeface.py:38-45) */
+  FP_RES_SHUFFLE2 = 4        /* ShuffleV2Block tail, cat + channel_shuffle(2) (y5/models/common.py:169-176,21-31): the op
+                                writes 2*Cout channels, out[2n] = res[n] (the other branch / pass-through half),
+                                out[2n+1] = act(conv)[n]; out_cmul = 1, 16-byte stores (vector epilogue only) */
 };
 
 /*
