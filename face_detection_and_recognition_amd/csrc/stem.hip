@@ -67,6 +67,13 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
   // staging of a tile's image rows: lane -> float4 slots tid + 256*j of the [nrows][Wp] image
   f32x4 pre[PF];
   unsigned premask = 0;
+  int srow[PF], sxp[PF];   // slot -> (row, column) of the staged image: the same for every tile
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int i = tid + 256 * j;
+    srow[j] = i / p.Wp;
+    sxp[j] = i - srow[j] * p.Wp;
+  }
   auto issue_stage = [&](int tile) {
     const int img = tile / p.tiles_per_img, tin = tile - img * p.tiles_per_img;
     const int m_lo = tin * TMS, m_hi = min(m_lo + TMS, p.OHW) - 1;
@@ -77,8 +84,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int i = tid + 256 * j;
-      const int row = i / p.Wp, xp = i - row * p.Wp;
-      const int iy = iy_lo + row, ix = xp - p.pad_l;
+      const int iy = iy_lo + srow[j], ix = sxp[j] - p.pad_l;
       const bool ok = i < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       pre[j] = *(const f32x4*)(ib + ((long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)) * 4);
       if (ok) premask |= 1u << j;
