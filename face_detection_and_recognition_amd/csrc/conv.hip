@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
     long m = m0 + r0 + 32 * i;
     rv[i] = m < p.M;
     if (PWD) {
-      pixbase[i] = (rv[i] ? m : 0) * p.in_ld + c4 * 4;
+      pixbase[i] = (rv[i] ? m : 0) * p.in_ld;
       iy0[i] = ix0[i] = 0;
     } else {
       const unsigned mm = rv[i] ? (unsigned)m : 0u;
@@ -97,33 +97,40 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
 
   f32x4 areg[4];
   f32x4 breg[NB];
+  unsigned amask = 0xfu;   // VEC gather: which of areg[] are real taps (the others are zero padding / tails)
+  unsigned bmask = 0;      // which of breg[] lie inside the packed weight block
   const int KHW = p.KH * p.KW;
 
   auto load_chunk = [&](int kbase) {
     if (PWD) {
+      const int kc = min(kbase + c4 * 4, p.K - 4);   // unconditional loads, masked when consumed (see below)
       const bool kv = kbase + c4 * 4 < p.K;
+      amask = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kv && rv[i]) v = *(const f32x4*)(p.in + pixbase[i] + kbase);
-        areg[i] = v;
+        areg[i] = *(const f32x4*)(p.in + pixbase[i] + kc);
+        if (kv && rv[i]) amask |= 1u << i;
       }
     } else if (VEC) {
-      const int k4 = kbase + c4 * 4;
-      const bool kv = k4 < p.K;
+      // Unconditional loads from clamped addresses; the padding / tail mask is applied in store_chunk, when the
+      // registers are consumed.  (A load behind `if (ok)` is waited for before the next one is issued, and a
+      // select right here would pull that wait in front of the MFMAs the loads are meant to hide under.)
+      const int k4 = min(kbase + c4 * 4, p.K - 4);
+      const bool kv = kbase + c4 * 4 < p.K;
       int tap = 0, c = k4;
       if (KHW > 1) {
         tap = k4 / p.Cin;
         c = k4 - tap * p.Cin;
       }
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      amask = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int iy = iy0[i] + ky, ix = ix0[i] + kx;
         const bool ok = kv && rv[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *(const f32x4*)(p.in + pixbase[i] + ((long)iy * p.W + ix) * p.in_ld + c);
-        areg[i] = v;
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        areg[i] = *(const f32x4*)(p.in + pixbase[i] + ((long)cy * p.W + cx) * p.in_ld + c);
+        if (ok) amask |= 1u << i;
       }
     } else {
 #pragma unroll
@@ -144,22 +151,32 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
       }
     }
     const int q0 = kbase >> 2;
+    bmask = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int idx = tid + 256 * j;
       const int q = idx / BN, col = idx - q * BN;
       const int gq = q0 + q, n = n0 + col;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gq < (p.Kpad >> 2) && n < p.Npad) v = *(const f32x4*)(p.w + ((long)gq * p.Npad + n) * 4);
-      breg[j] = v;
+      breg[j] = *(const f32x4*)(p.w + ((long)min(gq, (p.Kpad >> 2) - 1) * p.Npad + min(n, p.Npad - 1)) * 4);
+      if (gq < (p.Kpad >> 2) && n < p.Npad) bmask |= 1u << j;
     }
   };
 
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f32x4*)&As[(r0 + 32 * i) * LDA + c4 * 4] = areg[i];
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = areg[i];
+      if (VEC) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        v = ((amask >> i) & 1u) ? v : z4;
+      }
+      *(f32x4*)&As[(r0 + 32 * i) * LDA + c4 * 4] = v;
+    }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) *(f32x4*)&Bs[(tid + 256 * j) * 4] = breg[j];
+    for (int j = 0; j < NB; ++j) {
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)&Bs[(tid + 256 * j) * 4] = ((bmask >> j) & 1u) ? breg[j] : z4;
+    }
   };
 
   f32x16 acc[NB];
