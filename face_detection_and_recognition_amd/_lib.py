@@ -75,6 +75,7 @@ SIGNATURES = {
     "fp_cosine_filter": (_I, [_P, _P, _I64, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
     "fp_l2_mean_thres": (_I, [_P, _I, _I, _P, _P, _P]),
     "fp_l2_filter": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P]),
+    "fp_resize_standardize": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
     "fp_crop_resize_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),
     "fp_tracker_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
 }

@@ -175,3 +175,89 @@ extern "C" int fp_crop_resize_f32(const float* image_chw, int H, int W, const in
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// TF-style preprocess of the reference's FaceNet filter (similar_face_filtering/filter_faces_using_reference.py:60-68,
+// SURVEY row R1): u8 RGB -> [0,1] fp32 (convert_image_dtype) -> tf.image.resize bilinear (TF2: half-pixel centres, no
+// antialias) -> tf.image.per_image_standardization: (x - mean) / max(std, 1/sqrt(N)), N = oh*ow*3, population std.
+// Pass 1 resizes and accumulates sum / sum of squares per image in fp64 (wave shuffle + one atomicAdd per wave);
+// pass 2 normalises in place.  TF is absent offline; the standardisation formula is the reference's own test's
+// (sff/tests/base/test_similar_faces_filter.py:19-27), the resize is restated (parity unpinned).
+namespace {
+
+struct StdArgs {
+  const uint8_t* frames;  // [n][H][W][3]
+  float* out;             // [n][oh][ow][3]
+  double* stats;          // [n][2] sum, sum of squares (zeroed by the caller side of the C entry)
+  int n, H, W, oh, ow;
+};
+
+__global__ __launch_bounds__(256) void resize_f01_stats_kernel(StdArgs p) {
+  const int per = p.oh * p.ow;
+  const int img = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0, s2 = 0.0;
+  if (pix < per) {
+    const int dy = pix / p.ow, dx = pix - dy * p.ow;
+    const float sy = (float)p.H / (float)p.oh, sx = (float)p.W / (float)p.ow;
+    const float fy = ((float)dy + 0.5f) * sy - 0.5f, fx = ((float)dx + 0.5f) * sx - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), p.H - 1);
+    const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), p.W - 1);
+    const float ly = fy - fly, lx = fx - flx;
+    const uint8_t* f = p.frames + (long)img * p.H * p.W * 3;
+    float* o = p.out + ((long)img * per + pix) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float tl = f[((long)y0 * p.W + x0) * 3 + c] * (1.0f / 255.0f), tr = f[((long)y0 * p.W + x1) * 3 + c] * (1.0f / 255.0f);
+      const float bl = f[((long)y1 * p.W + x0) * 3 + c] * (1.0f / 255.0f), br = f[((long)y1 * p.W + x1) * 3 + c] * (1.0f / 255.0f);
+      const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+      const float v = top + (bot - top) * ly;
+      o[c] = v;
+      s += v;
+      s2 += (double)v * v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    s2 += __shfl_xor(s2, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&p.stats[img * 2 + 0], s);
+    atomicAdd(&p.stats[img * 2 + 1], s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void standardize_kernel(StdArgs p) {
+  const long per = (long)p.oh * p.ow * 3;
+  const int img = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per) return;
+  const double mean = p.stats[img * 2 + 0] / (double)per;
+  double var = p.stats[img * 2 + 1] / (double)per - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float adj = fmaxf((float)sqrt(var), 1.0f / sqrtf((float)per));
+  float* o = p.out + (long)img * per + i;
+  *o = (*o - (float)mean) / adj;
+}
+
+}  // namespace
+
+extern "C" int fp_resize_standardize(const uint8_t* frames, int n, int H, int W, float* out, int out_h, int out_w,
+                                     double* stats_scratch, void* stream) {
+  if (n < 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return FP_ERR_INVALID_ARG;
+  if (n == 0) return FP_OK;
+  if (!frames || !out || !stats_scratch) return FP_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stats_scratch, 0, sizeof(double) * 2 * n, s) != hipSuccess) {
+    fp_set_hip_error(hipGetLastError());
+    return FP_ERR_LAUNCH;
+  }
+  StdArgs a{frames, out, stats_scratch, n, H, W, out_h, out_w};
+  hipLaunchKernelGGL(resize_f01_stats_kernel, dim3((unsigned)fp_ceil_div((long)out_h * out_w, 256), (unsigned)n), dim3(256), 0, s, a);
+  FP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)fp_ceil_div((long)out_h * out_w * 3, 256), (unsigned)n), dim3(256), 0, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}

@@ -39,6 +39,34 @@ def read_image_bgr(img_path: str) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(Image.open(img_path).convert("RGB"))[..., ::-1])
 
 
+def preprocess_tf_standardize(frames_u8_rgb, in_size=(160, 160)):
+    """The TF FaceNet preprocess of the reference (filter_faces_using_reference.py:60-68 after decode_jpeg):
+    frames (n, H, W, 3) uint8 RGB on the device -> (n, h, w, 3) fp32, resized and per-image standardised by
+    fp_resize_standardize.  Selectable next to the Mobile-FaceNet preprocess ((x - 127.5) / 127.5 at 112x112)."""
+    import torch
+    from .. import _lib as L
+    f = frames_u8_rgb.contiguous()
+    if f.dtype != torch.uint8 or f.dim() != 4 or f.shape[-1] != 3 or f.device.type != "cuda":
+        raise ValueError("expected a (n, H, W, 3) uint8 tensor on the HIP device")
+    n, H, W, _ = f.shape
+    oh, ow = int(in_size[0]), int(in_size[1])
+    out = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=f.device)
+    stats = torch.empty((max(n, 1), 2), dtype=torch.float64, device=f.device)
+    L.check(L.load().fp_resize_standardize(L.ptr(f), n, H, W, L.ptr(out), oh, ow, L.ptr(stats), L.current_stream(f.device)),
+            "fp_resize_standardize")
+    return out
+
+
+def read_and_preprocess_img(img_path: str, in_size=(160, 160), dct_method: str = "INTEGER_FAST", device="cuda:0"):
+    """filter_faces_using_reference.py:60-68.  The JPEG is decoded on the host (PIL; dct_method is accepted for
+    signature compatibility), everything after it runs on the device.  Returns a (h, w, 3) fp32 device tensor."""
+    import torch
+    from PIL import Image
+    img = np.asarray(Image.open(img_path).convert("RGB"))
+    t = torch.from_numpy(np.ascontiguousarray(img)).to(str(device).replace("hip", "cuda")).unsqueeze(0)
+    return preprocess_tf_standardize(t, in_size)[0]
+
+
 def embed_images(model, paths, batch_size=32):
     """Decode on the host, then crop(whole image)+resize+normalise and embed on device, batch by batch."""
     dev = model._device()

@@ -284,6 +284,16 @@ int fp_l2_filter(const float* E, int64_t M, int D, const float* mean, const floa
                  float* dist, uint8_t* keep, void* stream);
 
 /*
+ * TF-style preprocess of the FaceNet filter (similar_face_filtering/filter_faces_using_reference.py:60-68):
+ * frames [n][H][W][3] u8 RGB -> [0,1] -> tf.image.resize bilinear (half-pixel centres, no antialias) to
+ * (out_h, out_w) -> per_image_standardization (x - mean)/max(std, 1/sqrt(out_h*out_w*3)).  out [n][out_h][out_w][3]
+ * fp32; stats_scratch = 2*n doubles of device scratch.  The formula is pinned by the reference's own test
+ * (sff/tests/base/test_similar_faces_filter.py:19-27); the resize is restated (TF absent offline).
+ */
+int fp_resize_standardize(const uint8_t* frames, int n, int H, int W, float* out, int out_h, int out_w,
+                          double* stats_scratch, void* stream);
+
+/*
  * Face crops from a float CHW image, the tail of the Triton python post-process model
  * (fde/modules/face_detection_trt_server/models/yolov5_face_postprocess/1/model.py:47-49,85-103): image (3,H,W) fp32
  * RGB in [0,1] -> *255, RGB->BGR -> crop [y:yh, x:xw] -> cv2.resize (float INTER_LINEAR) to (out_w, out_h) ->

@@ -134,3 +134,36 @@ def crop_face(frame, box, offsets=(-6, -1, 4, 5)):
     x, y, xw, yh = (int(v) for v in box)
     x, y, xw, yh = max(x + tx, 0), max(y + ty, 0), min(xw + bx, w), min(yh + by, h)
     return frame[y:yh, x:xw], (x, y, xw, yh)
+
+
+def tf_resize_bilinear(img_f32, size):
+    """tf.image.resize(img, size) for TF2 (bilinear, half_pixel_centers=True, antialias=False): img (H, W, C) fp32,
+    size (oh, ow).  Restated from TF's resize_bilinear_op (compute_interpolation_weights + lerp order): PARITY UNPINNED
+    (TensorFlow is absent offline)."""
+    H, W = img_f32.shape[:2]
+    oh, ow = size
+
+    def weights(o, i):
+        scale = np.float32(i) / np.float32(o)
+        f = (np.arange(o, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)
+        fl = np.floor(f)
+        lo = np.maximum(fl.astype(np.int64), 0)
+        hi = np.minimum(np.ceil(f).astype(np.int64), i - 1)
+        return lo, hi, (f - fl).astype(np.float32)
+
+    y0, y1, ly = weights(oh, H)
+    x0, x1, lx = weights(ow, W)
+    img = img_f32.astype(np.float32)
+    tl, tr = img[y0][:, x0], img[y0][:, x1]
+    bl, br = img[y1][:, x0], img[y1][:, x1]
+    top = tl + (tr - tl) * lx[None, :, None]
+    bot = bl + (br - bl) * lx[None, :, None]
+    return top + (bot - top) * ly[:, None, None]
+
+
+def read_and_preprocess_rgb(img_u8_rgb, in_size=(160, 160)):
+    """similar_face_filtering/filter_faces_using_reference.py:60-68 after the JPEG decode: convert_image_dtype ->
+    resize -> per_image_standardization (formula pinned by sff/tests/base/test_similar_faces_filter.py:19-27)."""
+    x = img_u8_rgb.astype(np.float32) * np.float32(1.0 / 255.0)
+    x = tf_resize_bilinear(x, in_size)
+    return standardize_image(x)

@@ -246,3 +246,25 @@ def test_triton_postprocess_contract_matches_oracle(dev, n_faces):
         assert len(boxes) == n_faces and faces.shape[1:] == (3, 112, 112)
     else:
         assert faces.shape == (1, 3, 112, 112) and boxes.tolist() == [[0, 0, 0, 0]]
+
+
+def test_tf_style_preprocess_matches_oracle_and_reference_test_property(dev):
+    """fp_resize_standardize (filter_faces_using_reference.py:60-68) against oracle/image_ref.py, and the
+    property the reference's own test pins (sff/tests/base/test_similar_faces_filter.py:19-27): at the native size the
+    result equals (img - mean)/max(std, 1/sqrt(N)) of the uint8 image within 1e-4."""
+    from face_detection_and_recognition_amd.similar_face_filtering.filter_faces_using_reference import \
+        preprocess_tf_standardize
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, (3, 97, 131, 3), dtype=np.uint8)
+    got = preprocess_tf_standardize(torch.from_numpy(frames).to(dev), (160, 160)).cpu().numpy()
+    for i in range(3):
+        np.testing.assert_allclose(got[i], image_ref.read_and_preprocess_rgb(frames[i], (160, 160)), rtol=0, atol=1e-4)  # fma in the lerp
+    same = rng.integers(0, 256, (2, 160, 160, 3), dtype=np.uint8)
+    got = preprocess_tf_standardize(torch.from_numpy(same).to(dev), (160, 160)).cpu().numpy()
+    for i in range(2):
+        img = same[i]
+        n = img.size
+        ref = (img - np.mean(img)) / max(np.std(img), 1 / (n ** 0.5))
+        assert np.allclose(got[i], ref, atol=1e-4)
+    const = np.full((1, 40, 40, 3), 77, np.uint8)                         # std = 0 -> divided by 1/sqrt(N), all zeros
+    assert np.abs(preprocess_tf_standardize(torch.from_numpy(const).to(dev), (160, 160)).cpu().numpy()).max() < 1e-4
