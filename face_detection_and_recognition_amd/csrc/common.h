@@ -5,6 +5,12 @@
 #include "../../include/facepath.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Pins the ISSUE ORDER of MFMAs (everything else may still move across): hipcc regroups v_mfma instructions by
+// accumulator, and a 32x32x2 f32 MFMA that accumulates into the previous MFMA's result issues at HALF rate (128 instead
+// of 64 cycles, tools/lab/mfma_chain_lab.hip).  Sources write the MFMAs round-robin over >= 2 accumulators and put
+// this after each one.  Mask = every class but MFMA / generic-ALU may be scheduled across (LLVM sched_barrier bits).
+#define FP_MFMA_ORDER() __builtin_amdgcn_sched_barrier(0x7F6)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FP_WAVE 64

@@ -119,12 +119,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pws_kernel(PwsArgs p) {
 #pragma unroll
       for (int kq = 0; kq < KC / 8; ++kq) {
         const f32x4 a = *(const f32x4*)(arow + kq * 8);
+        f32x4 bv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const f32x4 bv = *(const f32x4*)&Bs[((c * (KC / 4) + kq * 2 + h) * BN + nb * 32 + lr) * 4];
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const f32x4*)&Bs[((c * (KC / 4) + kq * 2 + h) * BN + nb * 32 + lr) * 4];
+        // round-robin over the NB accumulators: an MFMA that accumulates into the previous one's result waits for it
+        // (back-to-back dependent 32x32x2 issue), four independent chains keep the pipe full
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc[nb], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[nb][e], acc[nb], 0, 0, 0);
+            FP_MFMA_ORDER();
+          }
       }
     }
 
