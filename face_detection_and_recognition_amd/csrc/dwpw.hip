@@ -91,17 +91,28 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const int g0 = ch * KCH;
     // stage this chunk's projection weights and depthwise parameters
-    for (int i = tid; i < (KCH / 4) * BN; i += 256) {
-      const int q = i / BN, col = i - q * BN;
-      f32x4 v = z;
-      if (col < p.Npad) v = *(const f32x4*)(p.pwp + ((long)(g0 / 4 + q) * p.Npad + col) * 4);
-      *(f32x4*)&Bs[i * 4] = v;
-    }
-    for (int i = tid; i < 12 * (KCH / 4); i += 256) {
-      const int row = i / (KCH / 4), c4 = i - row * (KCH / 4);  // rows 0..8 taps, 9 scale, 10 bias, 11 slope
-      f32x4 v = z;
-      if (row < 11 || p.has_slope) v = *(const f32x4*)(p.dwp + (long)row * p.G + g0 + c4 * 4);
-      *(f32x4*)&Ws[i * 4] = v;
+    {
+      // all staging loads first (unconditional, clamped), then the LDS writes: a load -> wait -> ds_write loop costs
+      // one L2 round trip per 256 float4s (NB*2 + 1 of them per chunk)
+      constexpr int NWB = (KCH / 4) * BN / 256;   // = NB * 2
+      f32x4 wv[NWB], dv;
+#pragma unroll
+      for (int j = 0; j < NWB; ++j) {
+        const int i = tid + 256 * j;
+        const int q = i / BN, col = i - q * BN;
+        wv[j] = *(const f32x4*)(p.pwp + ((long)(g0 / 4 + q) * p.Npad + min(col, p.Npad - 1)) * 4);
+      }
+      const int di = min(tid, 12 * (KCH / 4) - 1);
+      const int drow = di / (KCH / 4), dc4 = di - drow * (KCH / 4);  // rows 0..8 taps, 9 scale, 10 bias, 11 slope
+      const bool dslope = drow == 11 && !p.has_slope;                // no PReLU: the slope row is not in the blob
+      dv = *(const f32x4*)(p.dwp + (long)(dslope ? 10 : drow) * p.G + g0 + dc4 * 4);
+#pragma unroll
+      for (int j = 0; j < NWB; ++j) {
+        const int i = tid + 256 * j;
+        const int col = i % BN;
+        *(f32x4*)&Bs[i * 4] = col < p.Npad ? wv[j] : z;
+      }
+      if (tid < 12 * (KCH / 4)) *(f32x4*)&Ws[tid * 4] = dslope ? z : dv;
     }
     __syncthreads();
 
