@@ -8,13 +8,22 @@ batch 256 per GPU (BASELINE.json configs[1]: BlazeFace back-camera 256^2 -> Mobi
 
 One step = one pass of the hot path over one batch of 256 frames already resident in HBM: letterbox+normalise ->
 BlazeFace-back forward -> anchor decode -> weighted NMS -> detections-to-crops -> crop/resize/normalise ->
-Mobile-FaceNet -> cosine filter against a 10k-row reference set (N > 1: + RCCL all_gather of the step's embedding
-matrix).  Frames shard by image: every rank processes its own 256 frames (weak scaling), no other collective.
-Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` (dominant kernel, HIP events
+Mobile-FaceNet -> cosine filter against a 10k-row reference set.  Workload as SURVEY 8(d) defines it: ~64 candidates
+per frame before NMS, ~2 faces per frame after it (two textured patches per frame); the step rotates through
+N_BATCHES different frame batches (seed + batch index), so no step re-reads the previous step's frames.
+N > 1: frames shard by image, every rank processes its own 256 frames per step (weak scaling, no data-path
+collective) and the similarity stage's exchange runs as north_star names it: RCCL all_gather of the step's embedding
+matrix (fixed-capacity blocks + device-side counts, no host round trip), then every rank matches its faces against the
+faces of all other ranks with the same HIP cosine kernel (face_detection_and_recognition_amd/distributed.py).
+Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` (dominant kernel family, HIP events
 recorded on the launch stream during the timed steps) and `cpu_baseline` (the oracle timed on the host cores).
+
+  --workload c5: BASELINE configs[4], the sharded similarity filter alone: 125 k gallery rows per rank x 10 k reference
+  rows (10 k / N produced per rank, one all_gather of equal blocks), fused row-max cosine kernel.
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -25,14 +34,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from face_detection_and_recognition_amd import similarity as S  # noqa: E402
 from face_detection_and_recognition_amd import workload as W  # noqa: E402
 from face_detection_and_recognition_amd.pipeline import FacePipeline  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 B_FRAMES = 256
+N_BATCHES = 4              # distinct frame batches the timed steps rotate through
 N_REF = 10000
-EMB_CAP_ROWS = 4096        # all_gather buffer rows per rank (>= faces per step per rank)
+EMB_CAP_ROWS = 1024        # all_gather block rows per rank (>= faces per step per rank; ~512 at 2 faces / frame)
 FRAME_BYTES = 576 * 1024 * 3
+LETTERBOX_OUT_BYTES = 256 * 256 * 3 * 4
 
 
 def host_cores():
@@ -87,15 +100,21 @@ def cpu_baseline(det_model, emb_model, ref, frames_cpu, tau, budget_s=25.0):
     return n_faces / dt, n_faces, n_frames, dt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the bounded CPU-baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def latest_pmc_traffic():
+    """(file name, {kernel family: hbm bytes per launch}) of the newest committed PMC summary, or (None, {}).
+    The figures come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
+    (gfx950: FETCH_SIZE doubled, MI355X_MICROARCH.md), summarised by tools/profile_summary.py -- they are NOT measured
+    in this run, which is why the JSON line names the file."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, {}
+    try:
+        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))
+    except Exception:
+        return None, {}
 
+
+def init_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,122 +133,154 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    return world, rank, dev, dist, backend
+
+
+def reduce_time_and_count(elapsed, count, world, dist, dev, backend):
+    """MAX of the elapsed time and SUM of the processed units over ranks."""
+    if world == 1:
+        return elapsed, float(count)
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    fsum = torch.tensor([float(count)], dtype=torch.float64, device=rdev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
+    return float(tmax), float(fsum)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def run_pipeline(args):
+    world, rank, dev, dist, backend = init_dist()
 
     # ---- workload (off the clock) ----
-    frames = W.make_frames(B_FRAMES, dev, seed=1234 + rank)
-    det = W.build_detector(dev, W.make_frames(64, dev, seed=999))   # same calibration on every rank
+    batches = [W.make_frames(B_FRAMES, dev, seed=1234 + 97 * rank + b) for b in range(N_BATCHES)]
+    det = W.build_detector(dev, W.make_frames(64, dev, seed=999), box_px=args.box_px)   # same calibration on every rank
     emb = W.build_embedder(dev)
+    emb._plans.max_plans = 8                   # a few 64-row buckets of face counts may alternate between batches
     ref = W.make_reference(N_REF, dev)
     pipe = FacePipeline(det, emb, ref, tau=0.3)
-    gather_buf = gather_out = None
+    gather_block = n_dev = None
     if world > 1:
-        gather_buf = torch.zeros((EMB_CAP_ROWS, emb.embedding_size), device=dev)
-        gather_out = torch.empty((world * EMB_CAP_ROWS, emb.embedding_size), device=dev)
+        from face_detection_and_recognition_amd import distributed as D
+        gather_block = torch.zeros((EMB_CAP_ROWS, emb.embedding_size), device=dev)
+        n_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
 
-    def step():
-        out = pipe.step(frames)
+    def to_comm(t):
+        return t if backend == "nccl" else t.cpu()
+
+    def step(k):
+        out = pipe.step(batches[k % N_BATCHES])
+        n = out["n_faces"]
         if world > 1:
-            n = out["n_faces"]
-            gather_buf[:n].copy_(out["emb"])
-            dist.all_gather_into_tensor(gather_out, gather_buf)     # RCCL over xGMI: the step's embedding matrix
-        return out["n_faces"]
+            if n > EMB_CAP_ROWS:
+                raise RuntimeError(f"{n} faces in one step exceed the all_gather block of {EMB_CAP_ROWS} rows")
+            gather_block[:n].copy_(out["emb"])
+            n_dev.fill_(n)
+            if backend == "nccl":           # RCCL over xGMI + the HIP cosine kernel on the gathered matrix
+                D.cross_rank_match(gather_block, n_dev, pipe.tau,
+                                   lambda G, R, tau, rinv: S.cosine_filter(G, R, tau, rinv=rinv), S.row_inv_norm)
+            else:                           # gloo rehearsal: collectives on host copies, kernel on the device
+                D.cross_rank_match(to_comm(gather_block), to_comm(n_dev), pipe.tau,
+                                   lambda G, R, tau, rinv: S.cosine_filter(G.to(dev), R.to(dev), tau, rinv=rinv.to(dev)),
+                                   lambda R: S.row_inv_norm(R.to(dev)).cpu())
+        return n
 
-    for _ in range(max(args.warmup, 1)):
-        nf = step()
+    nf_warm = []
+    for k in range(max(args.warmup, N_BATCHES)):       # every batch (and so every embedder bucket) is warmed once
+        nf_warm.append(step(k))
     torch.cuda.synchronize()
 
     # ---- per-op timers for the roofline figures ----
-    # HIP events around an op cost a little, so: one un-timed probe step with events on every op finds the
-    # dominant kernel family; the timed steps then carry events only on that family's launches.
+    # HIP events around an op cost a little, so: one un-timed probe pass over the batches with events on every op
+    # finds the dominant kernel family; the timed steps then carry events only on that family's launches.
     det_plan = det.net.plan_for(B_FRAMES)
-    n_pad = (nf + pipe.bucket - 1) // pipe.bucket * pipe.bucket
-    emb_plan = emb.plan_for(n_pad)
-    plans = {"blazeface": det_plan, "mobilefacenet": emb_plan}
-    probe = {k: p.new_timer() for k, p in plans.items()}
-    for name, p in plans.items():
-        p._timing = (probe[name], bytes([1] * p.n_ops))
-    step()
-    torch.cuda.synchronize()
+    emb_plans = list(emb._plans._plans.values())
+    plans = [det_plan] + emb_plans
     fam_ms = {}
-    for name, p in plans.items():
-        p._timing = None
-        ms0 = (ctypes.c_float * p.n_ops)()
-        p.accumulate(probe[name], ms0)
-        p.destroy_timer(probe[name])
-        for i in range(p.n_ops):
-            fam_ms[p.kernel_name(i)] = fam_ms.get(p.kernel_name(i), 0.0) + ms0[i]
+    for k in range(N_BATCHES):
+        probe = [p.new_timer() for p in plans]
+        for p, t in zip(plans, probe):
+            p._timing = (t, bytes([1] * p.n_ops))
+        step(k)
+        torch.cuda.synchronize()
+        for p, t in zip(plans, probe):
+            p._timing = None
+            ms0 = (ctypes.c_float * p.n_ops)()
+            p.accumulate(t, ms0)
+            p.destroy_timer(t)
+            for i in range(p.n_ops):
+                fam_ms[p.kernel_name(i)] = fam_ms.get(p.kernel_name(i), 0.0) + ms0[i]
     dom = max(fam_ms, key=fam_ms.get)
     probe_share = fam_ms[dom] / sum(fam_ms.values())
-    timers = {k: [p.new_timer() for _ in range(args.steps)] for k, p in plans.items()}
-    masks = {k: bytes([1 if p.kernel_name(i) == dom else 0 for i in range(p.n_ops)]) for k, p in plans.items()}
+    masks = [bytes([1 if p.kernel_name(i) == dom else 0 for i in range(p.n_ops)]) for p in plans]
+    timers = [[p.new_timer() for p in plans] for _ in range(args.steps)]
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     faces = 0
+    faces_per_step = []
     for k in range(args.steps):
-        for name, p in plans.items():
-            p._timing = (timers[name][k], masks[name])
-        faces += step()
+        for p, t, m in zip(plans, timers[k], masks):
+            p._timing = (t, m)
+        n = step(k)
+        faces += n
+        faces_per_step.append(n)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    for p in plans.values():
+    for p in plans:
         p._timing = None
 
-    elapsed = t1 - t0
-    tot = torch.tensor([elapsed, float(faces)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        fsum = tot[1:].clone()
-        dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
-        elapsed, faces_all = float(tmax), float(fsum)
-    else:
-        faces_all = float(faces)
+    elapsed, faces_all = reduce_time_and_count(t1 - t0, faces, world, dist, dev, backend)
 
-    # ---- roofline of the dominant kernel (rank 0) ----
+    # ---- roofline of the dominant kernel family (rank 0) ----
     roof = None
     if rank == 0:
-        ms_tot, launches, bytes_tot = 0.0, 0, 0
-        for name, p in plans.items():
-            ms = (ctypes.c_float * p.n_ops)()
-            for t in timers[name]:
+        ms_tot, launches, bytes_tot, pipe_bytes = 0.0, 0, 0.0, 0.0
+        for k in range(args.steps):
+            n_k = faces_per_step[k]
+            n_pad = (n_k + pipe.bucket - 1) // pipe.bucket * pipe.bucket
+            for p, t, m in zip(plans, timers[k], masks):
+                ms = (ctypes.c_float * p.n_ops)()
                 p.accumulate(t, ms)
                 p.destroy_timer(t)
-            for i in range(p.n_ops):
-                if masks[name][i]:
-                    ms_tot += ms[i]
-                    launches += args.steps
-                    bytes_tot += p.algorithmic_bytes(i) * args.steps
+                ran = p is det_plan or p.ops[0].N == n_pad
+                if not ran:
+                    continue
+                # Mobile-FaceNet runs on a batch padded to a multiple of 64 crops: algorithmic bytes count the REAL faces
+                real = 1.0 if p is det_plan else n_k / float(n_pad)
+                for i in range(p.n_ops):
+                    pipe_bytes += p.algorithmic_bytes(i) * real
+                    if m[i]:
+                        ms_tot += ms[i]
+                        launches += 1
+                        bytes_tot += p.algorithmic_bytes(i) * real
+        pipe_bytes = pipe_bytes / args.steps + B_FRAMES * (FRAME_BYTES + LETTERBOX_OUT_BYTES)
         achieved = bytes_tot / (ms_tot * 1e-3) / 1e9 if ms_tot > 0 else 0.0
-        # HBM bytes per launch from the committed PMC passes of this same command (profiles/*_pmc_traffic.json,
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH x2 correction), if present
-        traffic = None
-        try:
-            import glob
-            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
-            traffic = json.load(open(latest)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-        # whole-pipeline view: op-granular bytes of both networks + letterbox per step over the step time
-        pipe_bytes = sum(p.algorithmic_bytes(i) for p in plans.values() for i in range(p.n_ops)) + \
-            B_FRAMES * (FRAME_BYTES + 256 * 256 * 3 * 4)
+        avg_us = ms_tot * 1e3 / max(launches, 1)
+        src, table = latest_pmc_traffic()
+        traffic = table.get(dom, {}).get("hbm_bytes_per_launch")
+        step_s = elapsed / args.steps
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "pipeline_algorithmic_GBps": round(pipe_bytes / (elapsed / args.steps) / 1e9, 1),
-                "pipeline_frac": round(pipe_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                "avg_launch_us": round(ms_tot * 1e3 / launches, 2), "launches_per_step": launches // args.steps,
-                "algorithmic_bytes_per_launch": int(bytes_tot // launches),
-                "share_of_network_kernel_time": round(probe_share, 3)}
+                "traffic_source": (f"{src} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                   "not measured in this run)") if traffic is not None else None,
+                "hbm_frac_from_traffic": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                if traffic else None,
+                "avg_launch_us": round(avg_us, 2), "launches_per_step": round(launches / args.steps, 2),
+                "algorithmic_bytes_per_launch": int(bytes_tot / max(launches, 1)),
+                "share_of_network_kernel_time": round(probe_share, 3),
+                "pipeline_algorithmic_GBps": round(pipe_bytes / step_s / 1e9, 1),
+                "pipeline_frac": round(pipe_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, n_cpu, nfr, dt = cpu_baseline(det, emb, ref, frames[:args.cpu_frames].cpu(), pipe.tau)
+        v, n_cpu, nfr, dt = cpu_baseline(det, emb, ref, batches[0][:args.cpu_frames].cpu(), pipe.tau)
         cpu = {"value": round(v, 2), "unit": "faces/s", "cores": host_cores(), "kind": "port",
-               "sample": f"first {nfr} frames of the same batch (time-boxed), one frame per call like the reference: "
+               "sample": f"first {nfr} frames of batch 0 (time-boxed), one frame per call like the reference: "
                          f"{n_cpu} faces in {dt:.1f} s, torch-CPU fp32 oracle"}
 
     if rank == 0:
@@ -240,16 +291,97 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BlazeFace back-camera 256x256, batch 256 synthetic 576x1024 frames per GPU -> "
                                    "weighted NMS -> Mobile-FaceNet 112x112 -> cosine filter vs 10k x 512 reference",
-                       "frames_per_step_per_gpu": B_FRAMES, "faces_per_frame": round(faces_all / world / args.steps / B_FRAMES, 3),
+                       "frames_per_step_per_gpu": B_FRAMES, "frame_batches_rotated": N_BATCHES,
+                       "faces_per_frame": round(faces_all / world / args.steps / B_FRAMES, 3),
                        "frames_per_s": round(B_FRAMES * world * args.steps / elapsed, 1), "n_ref": N_REF,
                        "weights": "seeded synthetic (no weights ship with the reference)",
                        "parallelism": f"frames sharded by image, {world} rank(s), 1 per GPU" +
-                                      (", all_gather of the step's embeddings over RCCL" if world > 1 else "")},
+                                      (", all_gather of the step's embeddings over RCCL + cross-rank cosine match"
+                                       if world > 1 else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def run_c5(args):
+    """BASELINE configs[4]: gallery rows sharded 125 k per rank, 10 k reference rows produced sharded (10 k / N per
+    rank), one all_gather of the equal reference blocks, then the fused row-max cosine kernel on every rank's shard."""
+    world, rank, dev, dist, backend = init_dist()
+    M, D = args.gallery_rows, 512
+    nr_local = N_REF // world
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    G = torch.randn((M, D), device=dev, generator=g)
+    Rl = torch.randn((nr_local, D), device=dev, generator=g)
+    ginv = S.row_inv_norm(G)
+
+    def step():
+        if world > 1:
+            from face_detection_and_recognition_amd import distributed as Dm
+            if backend == "nccl":
+                return Dm.sharded_cosine_filter(G, Rl, 0.3, lambda a, b, tau: S.cosine_filter(a, b, tau, ginv=ginv),
+                                                equal_blocks=True)
+            return Dm.sharded_cosine_filter(G.cpu(), Rl.cpu(), 0.3,
+                                            lambda a, b, tau: S.cosine_filter(G, b.to(dev), tau, ginv=ginv),
+                                            equal_blocks=True)
+        return S.cosine_filter(G, Rl, 0.3, ginv=ginv)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        best, arg, keep = step()
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    nr = nr_local * world
+    elapsed, rows_all = reduce_time_and_count(t1 - t0, M * args.steps, world, dist, dev, backend)
+    if rank == 0:
+        ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+        tf = 2.0 * M * nr * D / (ms * 1e-3) / 1e12
+        line = {"metric": "pair-scores/sec, cosine filter gallery x reference x 512-d (fused row max, matrix never written)",
+                "value": round(rows_all * nr / elapsed, 1), "unit": "pair-scores/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"filter_faces_using_reference cosine mode: {M} gallery rows per GPU x {nr} reference "
+                                       f"rows x {D}-d, reference produced sharded ({nr_local} rows per rank)",
+                           "parallelism": f"gallery row-sharded over {world} rank(s)" +
+                                          (", one all_gather of the equal reference blocks over RCCL" if world > 1 else "")},
+                "roofline": {"bound": "mfma", "kernel": "cosine_tile_kernel", "achieved": round(tf, 1),
+                             "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFS, 4),
+                             "traffic": None, "note": "step = (all_gather +) cosine kernel + row-max finalisation, "
+                                                      "events on torch's current stream (the launch stream)"},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["pipeline", "c5"], default="pipeline")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--box-px", type=float, default=W.BOX_PX,
+                    help="synthetic detector's box size (model-input pixels); sets how candidates cluster in the NMS")
+    ap.add_argument("--gallery-rows", type=int, default=125_000, help="c5: gallery rows per rank")
+    args = ap.parse_args()
+    if args.workload == "c5":
+        run_c5(args)
+    else:
+        run_pipeline(args)
 
 
 if __name__ == "__main__":

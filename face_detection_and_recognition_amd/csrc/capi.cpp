@@ -40,7 +40,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const bool spatial = op.kind != FP_OP_L2NORM && op.kind != FP_OP_COPY;
   const int OH = spatial ? op.OH : op.H, OW = spatial ? op.OW : op.W;
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
-  const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW) ? op.Cout : op.Cin;
+  const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
+                    op.kind == FP_OP_YSTEM) ? op.Cout : op.Cin;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // input extent
   const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
@@ -52,7 +53,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
-      op.kind == FP_OP_DWPW) {
+      op.kind == FP_OP_DWPW || op.kind == FP_OP_YSTEM) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -87,6 +88,16 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.bias_off >= 0 && !span_ok(op.bias_off, (op.Cout + 3) / 4 * 4, weight_floats)) return FP_ERR_BOUNDS;
     if (op.bias_off >= 0 && op.res_mode != FP_RES_NONE) return FP_ERR_UNSUPPORTED;
   }
+  if (op.kind == FP_OP_YSTEM) {
+    if (op.Cin != 4 || op.res_C <= 0 || op.res_C > 32 || op.Cout > 32) return FP_ERR_UNSUPPORTED;
+    if (op.res_H <= 0 || op.res_W <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
+    const int nb2 = fp_ystem_nb2(op);
+    if (!span_ok(op.w_off, 40 * 32, weight_floats) || !span_ok(op.bias_off, 32, weight_floats)) return FP_ERR_BOUNDS;
+    if (op.scale_off >= 0 && !span_ok(op.scale_off, 32, weight_floats)) return FP_ERR_BOUNDS;
+    if (!span_ok(op.slope_off, (int64_t)nb2 * 16 * (32 + 2), weight_floats)) return FP_ERR_BOUNDS;
+    const int64_t res_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)op.res_H * op.res_W - 1) * op.res_ld + op.res_C;
+    if (!span_ok(op.res_off, res_ext, arena_floats)) return FP_ERR_BOUNDS;
+  }
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV) {
     if (op.scale_off >= 0 && !span_ok(op.scale_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
     if (op.bias_off >= 0 && !span_ok(op.bias_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
@@ -117,6 +128,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_L2NORM:
     case FP_OP_BLAZEBLOCK:
     case FP_OP_DWPW:
+    case FP_OP_YSTEM:
       return FP_OK;
     default:
       return FP_ERR_UNSUPPORTED;
@@ -164,6 +176,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;
+    case FP_OP_YSTEM:
+      snprintf(buf, sizeof(buf), "ystem_kernel<%d>", fp_ystem_nb2(*op));
+      return buf;
     default: return "?";
   }
 }
@@ -187,6 +202,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, hipStr
     case FP_OP_L2NORM: return fp_launch_l2norm(op, arena, s);
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
     case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
+    case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     default: return FP_ERR_UNSUPPORTED;
   }
 }

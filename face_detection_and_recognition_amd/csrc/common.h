@@ -44,4 +44,6 @@ bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take 
 int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)
 int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+int fp_ystem_nb2(const fp_op& op);
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd);  // conv_igemm template arguments for an op

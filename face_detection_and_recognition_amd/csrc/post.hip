@@ -393,7 +393,8 @@ __global__ __launch_bounds__(256) void yolo_nms_kernel(const float* __restrict__
 //        column reorder (blazeface/model.py:70) + get_dets_bboxes_confs_lmarks_areas (utils/inference.py:11-58).
 // fmt 1: YOLOv5-face rows (x1,y1,x2,y2,conf@4,...) in model-input pixels: get_bboxes_confs_areas
 //        (yolov5_face/onnx/onnx_utils.py:313-340).
-// Both: conf > det_thres, 100*area/(iw*ih) > area_thres, scale_coords (utils/image.py:79-99: subtract pad,
+// Both: conf > det_thres, area filter (fmt 0: 100*(area/total) > thr, info[6] = fraction; fmt 1: (100*area)/total > thr,
+// info[6] = percent -- each in its reference's operation order), scale_coords (utils/image.py:79-99: subtract pad,
 // divide by gain, clip to the frame), round half-to-even, then the crop of
 // face_extraction/extract_faces_from_dataset.py:289-303: int(), offsets (tx,ty,bx,by), clamp to the frame.
 // All fp32, in numpy's operation order for float32 inputs.  Faces are emitted in (frame, detection) order.
@@ -420,8 +421,13 @@ __device__ __forceinline__ bool crop_one(const CropArgs& p, const float* d, floa
     x1 = d[0]; y1 = d[1]; x2 = d[2]; y2 = d[3];
   }
   const float area = (x2 - x1) * (y2 - y1);
-  perc = area / (float)(p.in_w * p.in_h);
-  if (!(100.f * perc > p.area_thres)) return false;
+  if (p.fmt == 0) {  // inference.py:40-42: perc = area / total (the FRACTION is reported), filter on 100 * perc
+    perc = area / (float)(p.in_w * p.in_h);
+    if (!(100.f * perc > p.area_thres)) return false;
+  } else {           // onnx_utils.py:329-332: perc = 100 * area / total (the PERCENT is reported and compared)
+    perc = (100.f * area) / (float)(p.in_w * p.in_h);
+    if (!(perc > p.area_thres)) return false;
+  }
   x1 = (x1 - p.pad_x) / p.gain; x2 = (x2 - p.pad_x) / p.gain;
   y1 = (y1 - p.pad_y) / p.gain; y2 = (y2 - p.pad_y) / p.gain;
   x1 = fminf(fmaxf(x1, 0.f), (float)p.orig_w); x2 = fminf(fmaxf(x2, 0.f), (float)p.orig_w);

@@ -170,6 +170,7 @@ bool fp_pws_eligible(const fp_op& op) {
   if (op.KH != 1 || op.KW != 1 || op.stride != 1 || op.pad_t || op.pad_l) return false;
   if (op.OH != op.H || op.OW != op.W || op.out_cmul != 1) return false;
   if ((op.Cin != 64 && op.Cin != 128) || op.Cout % BN || op.Cout <= 0) return false;
+  if (8 * (op.Cout / BN) > 256) return false;   // the grid is a multiple of 8 * ntiles_n workgroups, at most 256
   const long HW = (long)op.H * op.W, M = (long)op.N * HW;
   if (op.in_ns != HW * op.in_ld || op.out_ns != HW * op.out_ld) return false;   // row m at base + m*ld
   if (op.in_ld % 4 || op.in_off % 4 || op.out_ld % 4 || op.out_off % 4 || op.w_off % 4) return false;
@@ -198,16 +199,14 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
   // K = 128: weights 64 KiB + 8 x 8.5 KiB = 132 KiB, 8 waves.  One workgroup per CU either way.
   const int waves = op.Cin == 64 ? 12 : 8;
   const size_t lds = 4 * ((size_t)op.Cin * BN + (size_t)waves * PRIV);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)pws_kernel<64, 12>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(4 * ((size_t)64 * BN + (size_t)12 * PRIV))) != hipSuccess ||
-        hipFuncSetAttribute((const void*)pws_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(4 * ((size_t)128 * BN + (size_t)8 * PRIV))) != hipSuccess) {
-      fp_set_hip_error(hipGetLastError());
-      return FP_ERR_LAUNCH;
-    }
-    attr_set = true;
+  // more than the default 64 KiB of dynamic LDS: the opt-in is per device and idempotent, so it is made on every
+  // launch (a process-wide "done" flag would miss a second GPU and is not thread-safe)
+  const hipError_t ae = op.Cin == 64
+      ? hipFuncSetAttribute((const void*)pws_kernel<64, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+      : hipFuncSetAttribute((const void*)pws_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (ae != hipSuccess) {
+    fp_set_hip_error(ae);
+    return FP_ERR_LAUNCH;
   }
   // one workgroup per CU; the grid is a multiple of 8 * ntiles_n so that every XCD serves every N tile
   int grid = 256;

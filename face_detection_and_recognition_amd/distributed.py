@@ -19,12 +19,13 @@ def shard_range(n_items, rank, world):
 
 def all_gather_rows(local_rows, group=None):
     """Gather row blocks of different lengths from every rank -> (all_rows, offsets).
-    Two collectives: the row counts (one int64 per rank) and the padded blocks."""
+    Two collectives: the row counts (one int64 per rank, read on the host in ONE transfer -- the result is ragged,
+    so the host has to know the sizes) and the padded blocks."""
     world = dist.get_world_size(group)
     n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts_t = torch.empty((world,), dtype=torch.int64, device=local_rows.device)
+    dist.all_gather_into_tensor(counts_t, n, group=group)
+    counts = counts_t.tolist()
     cap = max(max(counts), 1)
     padded = torch.zeros((cap,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
     padded[:local_rows.shape[0]] = local_rows
@@ -37,10 +38,54 @@ def all_gather_rows(local_rows, group=None):
     return rows, offsets
 
 
-def sharded_cosine_filter(local_gallery, local_reference, tau, filter_fn, group=None):
+def all_gather_blocks(block, n_valid, group=None):
+    """Variable-length gather with NO host round trip: every rank contributes a fixed-capacity block (cap, D) of which
+    the first ``n_valid`` rows (a 1-element device tensor) are meaningful.  Returns
+      rows  (world * cap, D)  -- rank r's rows at [r * cap, r * cap + count_r)
+      valid (world * cap,)    -- bool mask of the meaningful rows, built on device from the gathered counts
+      counts (world,) int64 device tensor.
+    Callers multiply their per-row quantities (inverse norms) by ``valid`` instead of compacting."""
+    world = dist.get_world_size(group)
+    cap = block.shape[0]
+    counts = torch.empty((world,), dtype=torch.int64, device=block.device)
+    dist.all_gather_into_tensor(counts, n_valid.to(torch.int64).reshape(1), group=group)
+    rows = torch.empty((world * cap,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(rows, block.contiguous(), group=group)
+    idx = torch.arange(world * cap, device=block.device)
+    valid = (idx % cap) < counts.repeat_interleave(cap)
+    return rows, valid, counts
+
+
+def cross_rank_match(block, n_valid, tau, filter_fn, inv_norm_fn, group=None):
+    """The pairwise-similarity exchange of the detect -> embed path (north_star: all-gather of the final embedding
+    matrix): every rank's faces of this step against the faces found by all OTHER ranks in the same step.
+    block (cap, D): this rank's embeddings, first n_valid rows meaningful (n_valid: 1-element device tensor).
+    filter_fn(G, R, tau, rinv) -> (best, arg, keep) is the cosine filter (HIP: similarity.cosine_filter);
+    inv_norm_fn(R) -> (rows,) inverse row norms.  Own rows and padding rows take part with inverse norm 0
+    (score 0), so nothing is compacted and nothing is read on the host.  Returns (best, arg, keep) for the cap local
+    rows (entries past n_valid are padding) and the gathered counts; arg indexes the gathered matrix (rank * cap + i)."""
+    rank = dist.get_rank(group)
+    cap = block.shape[0]
+    rows, valid, counts = all_gather_blocks(block, n_valid, group)
+    others = valid.clone()
+    others[rank * cap:(rank + 1) * cap] = False
+    rinv = inv_norm_fn(rows) * others.to(rows.dtype)
+    best, arg, keep = filter_fn(block, rows, tau, rinv)
+    return best, arg, keep, counts
+
+
+def sharded_cosine_filter(local_gallery, local_reference, tau, filter_fn, group=None, equal_blocks=False):
     """Each rank holds a gallery shard and the reference rows it embedded; returns this rank's
-    (best, arg, keep) against the FULL reference set (arg indexes the gathered reference)."""
-    full_ref, _ = all_gather_rows(local_reference, group)
+    (best, arg, keep) against the FULL reference set (arg indexes the gathered reference).
+    equal_blocks: every rank's reference block has the same number of rows (BASELINE configs[4]: 10 k rows / world)
+    -> ONE all_gather_into_tensor and no size exchange."""
+    if equal_blocks:
+        world = dist.get_world_size(group)
+        full_ref = torch.empty((world * local_reference.shape[0],) + tuple(local_reference.shape[1:]),
+                               dtype=local_reference.dtype, device=local_reference.device)
+        dist.all_gather_into_tensor(full_ref, local_reference.contiguous(), group=group)
+    else:
+        full_ref, _ = all_gather_rows(local_reference, group)
     return filter_fn(local_gallery, full_ref, tau)
 
 

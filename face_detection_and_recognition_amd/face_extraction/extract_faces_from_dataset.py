@@ -36,11 +36,10 @@ def extract_face_feat_conf_area_list(pipe, frames, frame_nums=None, times_sec=No
         frames = torch.from_numpy(np.ascontiguousarray(frames))
     frames = frames.to(pipe.dev)
     B, H, W, _ = frames.shape
-    dets, counts = pipe.detect(frames)
-    items, info, nf = pipe.crops(frames, dets, counts)
-    n = int(nf.item())
-    emb = pipe.embed(frames, items, n).cpu().numpy()
-    info = info[:n].cpu().numpy()
+    res = pipe.step(frames)                   # detect -> crops -> embed (+ the exact re-run on a detector overflow)
+    n = res["n_faces"]
+    emb = res["emb"].cpu().numpy()
+    info = res["info"].cpu().numpy()
     out = [FrameFacesObj(frame_nums[i] if frame_nums is not None else i,
                          times_sec[i] if times_sec is not None else 0.0, [], [], np.zeros((0, 4), np.float32))
            for i in range(B)]
@@ -50,7 +49,7 @@ def extract_face_feat_conf_area_list(pipe, frames, frame_nums=None, times_sec=No
         x1, y1, x2, y2, conf, area = info[k, 1:7]
         boxes[f].append([x1, y1, x2, y2])
         out[f].confs.append(float(conf))
-        out[f].areas.append(float(area))     # fraction of the model input (inference.py:37-44)
+        out[f].areas.append(float(area))     # BlazeFace: fraction (inference.py:40-46); YOLO: percent (onnx_utils.py:331)
         out[f].feats.append(emb[k])
     for f in range(B):
         if boxes[f]:

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...plan import Buf, CompiledPlan, PlanBuilder, View, cpad
+from ...plan import Buf, CompiledPlan, PlanBuilder, PlanCache, View, cpad
 from ..params import ConvParams, _NoCompute, npy
 
 
@@ -112,7 +112,7 @@ class BlazeFace(nn.Module):
             self.min_score_thresh = 0.75
         self.min_suppression_threshold = 0.3
         self.anchors = None
-        self._plans = {}
+        self._plans = PlanCache()
         self._define_layers()
 
     def _define_layers(self):
@@ -145,7 +145,7 @@ class BlazeFace(nn.Module):
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
-        self._plans = {}
+        self._plans.clear()
         return out
 
     def load_anchors(self, path, use_numpy=False):
@@ -159,7 +159,7 @@ class BlazeFace(nn.Module):
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._plans = {}
+        self._plans.clear()
         if self.anchors is not None:
             self.anchors = fn(self.anchors)
         return out
@@ -207,10 +207,10 @@ class BlazeFace(nn.Module):
         head(h, self.regressor_16, r_off, A * 16, 512, 16)
         return pb, inp, r_off, c_off
 
-    def _build(self, N):
+    def _build(self, N, cache=None):
         A = self.num_anchors
         pb, inp, r_off, c_off = self._emit(N)
-        plan = CompiledPlan(pb, self._device())
+        plan = CompiledPlan(pb, self._device(), cache)
         plan.inp = inp
         plan.r = plan.arena[r_off: r_off + N * A * 16].view(N, A, 16)
         plan.c = plan.arena[c_off: c_off + N * A].view(N, A, 1)
@@ -218,11 +218,9 @@ class BlazeFace(nn.Module):
         return plan
 
     def plan_for(self, N):
-        if N not in self._plans:
-            if self._device().type != "cuda":
-                raise L.FacepathError("BlazeFace runs only on a HIP device (model.to('cuda')); there is no CPU path")
-            self._plans[N] = self._build(N)
-        return self._plans[N]
+        if self._device().type != "cuda":
+            raise L.FacepathError("BlazeFace runs only on a HIP device (model.to('cuda')); there is no CPU path")
+        return self._plans.get(N, lambda cache: self._build(N, cache))
 
     # ------------------------------------------------------------------ inference
     def forward(self, x):
@@ -232,7 +230,7 @@ class BlazeFace(nn.Module):
         plan.input[..., :3].copy_(x.to(self._device(), torch.float32).permute(0, 2, 3, 1))
         plan.input[..., 3:].zero_()
         plan.run()
-        return [plan.r, plan.c]
+        return [plan.r.clone(), plan.c.clone()]     # plan.r / plan.c are arena views the next call overwrites
 
     def _preprocess_lut(self):
         # x.float() / 127.5 - 1.0 (blazeface.py:248-250), evaluated for the 256 u8 values in torch fp32
@@ -246,7 +244,8 @@ class BlazeFace(nn.Module):
         return self.predict_on_batch(img.unsqueeze(0))[0]
 
     def raw_from_u8_nhwc(self, frames_u8):
-        """(b, H, W, 3) u8 RGB on device, H/W = the model input size -> raw (r, c) of the HIP plan."""
+        """(b, H, W, 3) u8 RGB on device, H/W = the model input size -> raw (r, c) of the HIP plan.
+        Zero-copy: r and c are views into the plan arena, valid until the next run at this batch size."""
         b, H, W, _ = frames_u8.shape
         assert (H, W) == self.input_hw
         plan = self.plan_for(b)

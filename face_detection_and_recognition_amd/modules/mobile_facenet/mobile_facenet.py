@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...plan import CompiledPlan, PlanBuilder, bn_affine
+from ...plan import CompiledPlan, PlanBuilder, PlanCache, bn_affine
 from ..params import BNParams, ConvParams, LinearParams, PReLUParams, _NoCompute, npy
 
 
@@ -148,19 +148,19 @@ class MobileFaceNet(nn.Module):
         self.conv_6_flatten = Flatten()
         self.linear = LinearParams(512, embedding_size, bias=False)
         self.bn = BNParams(embedding_size)
-        self._plans = {}
+        self._plans = PlanCache()
 
     def _device(self):
         return self.linear.weight.device
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
-        self._plans = {}
+        self._plans.clear()
         return out
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._plans = {}
+        self._plans.clear()
         return out
 
     def _emit(self, N, H=112, W=112):
@@ -200,20 +200,18 @@ class MobileFaceNet(nn.Module):
         pb.l2norm(z.view(0, E), o.view(0, E))
         return pb, inp, o
 
-    def _build(self, N):
+    def _build(self, N, cache=None):
         E = self.embedding_size
         pb, inp, o = self._emit(N)
-        plan = CompiledPlan(pb, self._device())
+        plan = CompiledPlan(pb, self._device(), cache)
         plan.input = plan.buf_tensor(inp, N)
         plan.out = plan.buf_tensor(o, N).view(N, -1)[:, :E]
         return plan
 
     def plan_for(self, N):
-        if N not in self._plans:
-            if self._device().type != "cuda":
-                raise L.FacepathError("MobileFaceNet runs only on a HIP device (model.to('cuda')); there is no CPU path")
-            self._plans[N] = self._build(N)
-        return self._plans[N]
+        if self._device().type != "cuda":
+            raise L.FacepathError("MobileFaceNet runs only on a HIP device (model.to('cuda')); there is no CPU path")
+        return self._plans.get(N, lambda cache: self._build(N, cache))
 
     def forward(self, x):
         b = x.shape[0]
@@ -221,10 +219,11 @@ class MobileFaceNet(nn.Module):
         plan.input[..., :3].copy_(x.to(self._device(), torch.float32).permute(0, 2, 3, 1))
         plan.input[..., 3:].zero_()
         plan.run()
-        return plan.out
+        return plan.out.clone()                      # plan.out is an arena view the next call overwrites
 
     def embed_resident(self, n):
-        """Run the plan on whatever fp_resize_normalize wrote into plan_for(n).input; returns (n, E)."""
+        """Run the plan on whatever fp_resize_normalize wrote into plan_for(n).input; returns (n, E).
+        Zero-copy: the result is a view into the plan arena, valid until the next run at this batch size."""
         plan = self.plan_for(n)
         plan.run()
         return plan.out

@@ -6,6 +6,7 @@ import torch
 
 from ..models.base import Model
 from . import nms_face_device, preprocess_batch
+from .general import MAX_DET
 
 
 class YOLOV5FaceModel(Model):
@@ -31,14 +32,17 @@ class YOLOV5FaceModel(Model):
             detections = np.zeros((0, 5), dtype=np.float32)   # the reference returns an uninitialised (0, 5) array
         return detections
 
-    def raw_batch(self, frames):
-        """frames (B, H, W, 3) u8 BGR -> device dets (B, max_det, 16) in input pixels, counts (B,)."""
+    def raw_batch(self, frames, max_det=MAX_DET):
+        """frames (B, H, W, 3) u8 BGR -> device dets (B, max_det, 16) in input pixels, counts (B,), overflow (B,).
+        overflow[i] != 0: image i had more than max_det survivors and was truncated; the caller re-runs with
+        ``max_det=None`` (no cap, as non_max_suppression_face does) -- FacePipeline.step reads the flag in the same
+        host transfer as the face count."""
         dev = self.net._device()
         if isinstance(frames, np.ndarray):
             frames = torch.from_numpy(np.ascontiguousarray(frames))
         frames = frames.to(dev)
         plan = preprocess_batch(self.net, frames, self.input_size)
         z = self.net.run_plan(plan)
-        out, cnt, _, over = nms_face_device(z, conf_thres=0.4, iou_thres=0.5)
-        self._last_overflow = over
-        return out, cnt
+        out, cnt, _, over = nms_face_device(z, conf_thres=0.4, iou_thres=0.5,
+                                            max_det=z.shape[1] if max_det is None else max_det)
+        return out, cnt, over

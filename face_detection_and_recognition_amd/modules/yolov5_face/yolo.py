@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...plan import CompiledPlan, PlanBuilder, View, bn_affine, cpad
+from ...plan import CompiledPlan, PlanBuilder, PlanCache, View, bn_affine, cpad
 from ..params import BNParams, ConvParams, _NoCompute, npy
 
 # Architecture specs of the reference's in-tree yamls (y5/models/yolov5n.yaml, yolov5s.yaml, yolov5n-0.5.yaml):
@@ -126,7 +126,33 @@ class StemBlock(_NoCompute):
         self.stem_2b = Conv(c2 // 2, c2, 3, 2, 1)
         self.stem_3 = Conv(c2 * 2, c2, 1, 1, 0)
 
-    def emit(self, pb, x):
+    FUSE = True   # class-wide switch: False emits the five separate ops (A/B parity tests)
+
+    @staticmethod
+    def _sb(conv):
+        """(scale, bias) of a Conv's epilogue: live BatchNorm affine, or (None, folded bias) after fuse()."""
+        if conv.bn is None:
+            return None, npy(conv.conv.bias)
+        return _bn_sb(conv.bn)
+
+    def emit(self, pb, x, out=None):
+        c = self.c2
+        s1c = self.stem_1
+        if (StemBlock.FUSE and x.C == 4 and x.buf.ld == 4 and x.coff == 0 and x.H % 4 == 0 and x.W % 4 == 0 and
+                c <= 32 and c % 8 == 0 and s1c.k == 3 and s1c.s == 2 and s1c.p == 1 and s1c.act and self.stem_2a.act):
+            # stem_1 -> (LDS) -> stem_2a + maxpool in one kernel (FP_OP_YSTEM): stem_1's output never reaches HBM
+            H1, W1 = x.H // 2, x.W // 2
+            a = pb.new_buf(H1, W1, c // 2)
+            cat = pb.new_buf(H1 // 2, W1 // 2, 2 * c)
+            sc1, bi1 = self._sb(s1c)
+            sc2, bi2 = self._sb(self.stem_2a)
+            pb.ystem(x, npy(s1c.conv.weight), sc1, bi1, npy(self.stem_2a.conv.weight), sc2, bi2, a.view(0, cpad(c // 2)),
+                     cat.view(c, c))
+            self.stem_2b.emit(pb, a.view(0, c // 2), out=cat.view(0, c))
+            pb.free(a)
+            y = self.stem_3.emit(pb, cat.view(), out=out)
+            pb.free(cat)
+            return y
         s1 = self.stem_1.emit(pb, x)
         a = self.stem_2a.emit(pb, s1)
         OH, OW = math.ceil(s1.H / 2), math.ceil(s1.W / 2)            # MaxPool2d(2, 2, ceil_mode=True)
@@ -135,7 +161,7 @@ class StemBlock(_NoCompute):
         pb.maxpool(s1, cat.view(self.c2, self.c2), 2, 2, 0)
         pb.free(a.buf)
         pb.free(s1.buf)
-        y = self.stem_3.emit(pb, cat.view())
+        y = self.stem_3.emit(pb, cat.view(), out=out)
         pb.free(cat)
         return y
 
@@ -169,7 +195,7 @@ class C3(_NoCompute):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
-    def emit(self, pb, x):
+    def emit(self, pb, x, out=None):
         assert self.c_ % 4 == 0, "C3 hidden width must be a multiple of 4 for the in-place concat"
         cat = pb.new_buf(x.H, x.W, 2 * self.c_)
         t = self.cv1.emit(pb, x)
@@ -179,7 +205,7 @@ class C3(_NoCompute):
             pb.free(t.buf)
             t = y
         self.cv2.emit(pb, x, out=cat.view(self.c_, self.c_))
-        out = self.cv3.emit(pb, cat.view())
+        out = self.cv3.emit(pb, cat.view(), out=out)
         pb.free(cat)
         return out
 
@@ -208,10 +234,13 @@ class ShuffleV2Block(_NoCompute):
                                      ConvParams(bf, bf, 3, stride, 1, groups=bf, bias=False), BNParams(bf, eps=1e-3),
                                      ConvParams(bf, bf, 1, 1, 0, bias=False), BNParams(bf, eps=1e-3), _Tag())
 
-    def emit(self, pb, x):
+    def emit(self, pb, x, out=None):
+        """out: optional View (C = oup) the block writes into, e.g. a channel slice of a later Concat's buffer."""
         s = self.stride
         OH, OW = (x.H + 2 - 3) // s + 1, (x.W + 2 - 3) // s + 1
-        out = pb.new_buf(OH, OW, self.oup)
+        out = pb.new_buf(OH, OW, self.oup).view() if out is None else out
+        assert out.C == self.oup and out.cmul == 1
+        ob, oc = out.buf, out.coff
         # cat + channel_shuffle(2) is the last conv's epilogue (FP_RES_SHUFFLE2): out[2n] = other half, out[2n+1] = conv
         b2 = self.branch2
         if s == 1:
@@ -238,15 +267,15 @@ class ShuffleV2Block(_NoCompute):
         pb.free(t1)
         sc, bi = _bn_sb(b2[6])
         if self.bf % 4 == 0:
-            pb.conv(t2.view(), npy(b2[5].weight), out.view(0, self.bf), scale=sc, bias=bi, act=L.ACT_SILU,
+            pb.conv(t2.view(), npy(b2[5].weight), View(ob, oc, self.bf), scale=sc, bias=bi, act=L.ACT_SILU,
                     res=first, res_mode=L.RES_SHUFFLE2)
         else:   # odd widths: scalar interleaved writes
-            pb.copy(first, out.view(0, self.bf, cmul=2))
-            pb.conv(t2.view(), npy(b2[5].weight), out.view(1, self.bf, cmul=2), scale=sc, bias=bi, act=L.ACT_SILU)
+            pb.copy(first, View(ob, oc, self.bf, cmul=2))
+            pb.conv(t2.view(), npy(b2[5].weight), View(ob, oc + 1, self.bf, cmul=2), scale=sc, bias=bi, act=L.ACT_SILU)
         if b1out is not None:
             pb.free(b1out)
         pb.free(t2)
-        return out.view()
+        return out
 
 
 class SPP(_NoCompute):
@@ -259,22 +288,22 @@ class SPP(_NoCompute):
         self.cv1 = Conv(c1, c_, 1, 1)
         self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
 
-    def emit(self, pb, x):
+    def emit(self, pb, x, out=None):
         assert self.c_ % 4 == 0
         cat = pb.new_buf(x.H, x.W, self.c_ * (len(self.k) + 1))
         first = cat.view(0, self.c_)
         self.cv1.emit(pb, x, out=first)
         for i, k in enumerate(self.k):
             pb.maxpool(first, cat.view(self.c_ * (i + 1), self.c_), k, 1, k // 2)
-        y = self.cv2.emit(pb, cat.view())
+        y = self.cv2.emit(pb, cat.view(), out=out)
         pb.free(cat)
         return y
 
 
 class Upsample(_NoCompute):
-    def emit(self, pb, x):
-        out = pb.new_buf(2 * x.H, 2 * x.W, x.C)
-        return pb.upsample2x(x, out.view(0, x.C))
+    def emit(self, pb, x, out=None):
+        out = pb.new_buf(2 * x.H, 2 * x.W, x.C).view(0, x.C) if out is None else out
+        return pb.upsample2x(x, out)
 
 
 class Concat(_NoCompute):
@@ -284,15 +313,19 @@ class Concat(_NoCompute):
         super().__init__()
         self.d = dimension
 
-    def emit(self, pb, xs):
+    def emit(self, pb, xs, out=None):
+        """out: the buffer view the producers were told to write into (Model._emit places concat inputs at their
+        channel offset when they are produced, so the concat is pure addressing); inputs that are not already in
+        place are copied."""
         C = sum(v.C for v in xs)
-        out = pb.new_buf(xs[0].H, xs[0].W, C)
+        out = pb.new_buf(xs[0].H, xs[0].W, C).view() if out is None else out
         off = 0
         for v in xs:
             assert v.C % 4 == 0
-            pb.copy(v, out.view(off, v.C))
+            if not (v.buf is out.buf and v.coff == out.coff + off and v.cmul == 1):
+                pb.copy(v, View(out.buf, out.coff + off, v.C))
             off += v.C
-        return out.view()
+        return out
 
 
 class Detect(_NoCompute):
@@ -329,21 +362,21 @@ class Model(nn.Module):
             self.yaml = SPECS[name]
         if nc and nc != self.yaml["nc"]:
             self.yaml = dict(self.yaml, nc=nc)
-        self.model, self.save = parse_model(self.yaml, [ch])
+        self.model, self.save, self.ch_out = parse_model(self.yaml, [ch])
         m = self.model[-1]
         # strides of the three levels (the reference measures them with a dry forward pass, yolo.py:140-146)
         m.stride = torch.tensor([8., 16., 32.])
         m.anchors = m.anchors / m.stride.view(-1, 1, 1)
         self.stride = m.stride
         self.names = [str(i) for i in range(self.yaml["nc"])]
-        self._plans = {}
+        self._plans = PlanCache()
 
     # ---- reference API ----
     def fuse(self):
         for mod in self.model.modules():
             if isinstance(mod, Conv):
                 mod.fuse()
-        self._plans = {}
+        self._plans.clear()
         return self
 
     def float(self):
@@ -355,33 +388,54 @@ class Model(nn.Module):
                 if isinstance(mod, Conv):
                     mod.make_fused_structure()
         out = super().load_state_dict(sd, *a, **k)
-        self._plans = {}
+        self._plans.clear()
         return out
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._plans = {}
+        self._plans.clear()
         return out
 
     def _device(self):
         return self.model[-1].m[0].weight.device
 
     # ---- plan ----
+    CONCAT_IN_PLACE = True   # class-wide switch: False copies every Concat input (A/B parity tests)
+
     def _emit(self, N, H=640, W=640):
         assert H % 32 == 0 and W % 32 == 0
         pb = PlanBuilder(N)
         inp = pb.new_buf(H, W, 3)
         det = self.model[-1]
+        layers = list(self.model)
+
+        def srcs(m):
+            return [m.i - 1 if j == -1 else j for j in ([m.f] if isinstance(m.f, int) else m.f)]
+
         # liveness: layer j's output dies after the last layer that reads it
         last_use = {}
-        for m in self.model:
-            for j in ([m.f] if isinstance(m.f, int) else m.f):
-                src = m.i - 1 if j == -1 else j
+        for m in layers:
+            for src in srcs(m):
                 if src >= 0:
                     last_use[src] = m.i
+        # Concat as pure addressing (common.py:235-242): every input of a Concat is produced straight into its channel
+        # slice of the concat buffer, which is allocated when the first of them is produced (at most one Concat per
+        # producer; an input that feeds two Concats is copied into the second)
+        place = {}        # producer layer index -> (concat layer index, position among its inputs)
+        if Model.CONCAT_IN_PLACE:
+            for m in layers:
+                if isinstance(m, Concat):
+                    for pos, src in enumerate(srcs(m)):
+                        prod = layers[src]
+                        last = prod[-1] if isinstance(prod, nn.Sequential) else prod
+                        if src >= 0 and src not in place and isinstance(last, (Conv, C3, ShuffleV2Block, SPP, StemBlock,
+                                                                              Upsample)):
+                            place[src] = (m.i, pos)
+        cat_bufs = {}     # concat layer index -> Buf
+
         outs = {}
         heads = []
-        for m in self.model:
+        for m in layers:
             fs = [m.f] if isinstance(m.f, int) else m.f
             ins = [inp.view() if (j == -1 and m.i == 0) else outs[m.i - 1 if j == -1 else j] for j in fs]
             if isinstance(m, Detect):
@@ -390,27 +444,66 @@ class Model(nn.Module):
                     pb.conv(src, npy(conv.weight), hb.view(0, det.no * det.na), bias=npy(conv.bias))
                     heads.append(hb)
                 break
+            target = None
+            if isinstance(m, Concat):
+                if m.i in cat_bufs:
+                    target = cat_bufs[m.i].view()
+            elif m.i in place:
+                cat_i, pos = place[m.i]
+                c_self = self.ch_out[m.i]
+                if cat_i not in cat_bufs:
+                    widths = [self.ch_out[src] for src in srcs(layers[cat_i])]     # parse_model's channel table
+                    if any(w % 4 for w in widths):
+                        del place[m.i]              # unaligned width: fall back to a copy
+                    else:
+                        oh, ow = self._out_hw(m, ins[0])
+                        cat_bufs[cat_i] = pb.new_buf(oh, ow, sum(widths))
+                        cat_bufs[cat_i].widths = widths
+                if m.i in place:
+                    cb = cat_bufs[cat_i]
+                    target = View(cb, sum(cb.widths[:pos]), c_self)
             xin = ins if isinstance(m, Concat) else ins[0]
             if isinstance(m, nn.Sequential):
                 y = xin
-                for sub in m:
-                    y2 = sub.emit(pb, y)
+                for k, sub in enumerate(m):
+                    y2 = sub.emit(pb, y, out=target) if (target is not None and k == len(m) - 1) else sub.emit(pb, y)
                     if y is not xin:
                         pb.free(y.buf)
                     y = y2
             else:
-                y = m.emit(pb, xin)
+                y = m.emit(pb, xin, out=target) if target is not None else m.emit(pb, xin)
             outs[m.i] = y
             for j, lu in last_use.items():
-                if lu == m.i and j in outs:
+                if lu == m.i and j in outs and not any(outs[j].buf is cb for cb in cat_bufs.values()):
                     pb.free(outs[j].buf)
+            for cat_i, cb in list(cat_bufs.items()):
+                # a concat buffer dies after the last reader of the Concat's output AND of every input placed in it
+                members = [cat_i] + [src for src, (ci, _) in place.items() if ci == cat_i]
+                if m.i == max(last_use.get(j, j) for j in members) and not getattr(cb, "freed", False):
+                    pb.free(cb)
+                    cb.freed = True
         n_rows = sum(det.na * hb.H * hb.W for hb in heads)
         z_off, _ = pb.new_raw(n_rows * det.no)
         return pb, inp, heads, z_off, n_rows
 
-    def _build(self, N, H, W):
+    @staticmethod
+    def _out_hw(m, x):
+        """Spatial size of module m's output for input view x."""
+        h, w = x.H, x.W
+        for sub in (m if isinstance(m, nn.Sequential) else [m]):
+            if isinstance(sub, Upsample):
+                h, w = 2 * h, 2 * w
+            elif isinstance(sub, ShuffleV2Block):
+                h, w = (h + 2 - 3) // sub.stride + 1, (w + 2 - 3) // sub.stride + 1
+            elif isinstance(sub, Conv):
+                h, w = (h + 2 * sub.p - sub.k) // sub.s + 1, (w + 2 * sub.p - sub.k) // sub.s + 1
+            elif isinstance(sub, StemBlock):
+                h, w = math.ceil(((h + 2 - 3) // 2 + 1) / 2), math.ceil(((w + 2 - 3) // 2 + 1) / 2)
+        return h, w
+
+    def _build(self, N, H, W, cache=None):
         pb, inp, heads, z_off, n_rows = self._emit(N, H, W)
-        plan = CompiledPlan(pb, self._device())
+        plan = CompiledPlan(pb, self._device(), cache)
         plan.input = plan.buf_tensor(inp, N)
         plan.heads = [plan.buf_tensor(hb, N) for hb in heads]
         plan.z = plan.arena[z_off: z_off + N * n_rows * 16].view(N, n_rows, 16)
@@ -418,15 +511,13 @@ class Model(nn.Module):
         return plan
 
     def plan_for(self, N, H=640, W=640):
-        key = (N, H, W)
-        if key not in self._plans:
-            if self._device().type != "cuda":
-                raise L.FacepathError("YOLOv5-face runs only on a HIP device (model.to('cuda')); there is no CPU path")
-            self._plans[key] = self._build(N, H, W)
-        return self._plans[key]
+        if self._device().type != "cuda":
+            raise L.FacepathError("YOLOv5-face runs only on a HIP device (model.to('cuda')); there is no CPU path")
+        return self._plans.get((N, H, W), lambda cache: self._build(N, H, W, cache))
 
     def run_plan(self, plan):
-        """Forward + Detect decode on whatever is in plan.input.  Returns z (N, n_rows, 16)."""
+        """Forward + Detect decode on whatever is in plan.input.  Returns z (N, n_rows, 16): zero-copy, a view into
+        the plan arena, valid until the next run of this plan."""
         plan.run()
         det = self.model[-1]
         lib = L.load()
@@ -446,9 +537,9 @@ class Model(nn.Module):
         plan = self.plan_for(b, H, W)
         plan.input[..., :3].copy_(x.to(self._device(), torch.float32).permute(0, 2, 3, 1))
         plan.input[..., 3:].zero_()
-        z = self.run_plan(plan)
+        z = self.run_plan(plan).clone()              # plan.z / plan.heads are arena views the next call overwrites
         det = self.model[-1]
-        heads = [h.view(b, h.shape[1], h.shape[2], det.na, det.no).permute(0, 3, 1, 2, 4) for h in plan.heads]
+        heads = [h.view(b, h.shape[1], h.shape[2], det.na, det.no).permute(0, 3, 1, 2, 4).clone() for h in plan.heads]
         return z, heads
 
 
@@ -486,7 +577,7 @@ def parse_model(d, ch):
         save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
         layers.append(m_)
         ch.append(c2)
-    return nn.Sequential(*layers), sorted(save)
+    return nn.Sequential(*layers), sorted(save), ch[1:]
 
 
 def attempt_load(weights, map_location=None, cfg=None):

@@ -45,9 +45,11 @@ class FacePipeline:
         self.rinv = None if reference is None else S.row_inv_norm(self.reference)
 
     # -- stages ----------------------------------------------------------------------------------
-    def detect(self, frames):
-        """frames (B, H, W, 3) u8 BGR on device -> (dets, counts, fmt, row_floats)."""
-        return self.det.raw_batch(frames)
+    def detect(self, frames, max_det=-1):
+        """frames (B, H, W, 3) u8 BGR on device -> (dets, counts, overflow or None).  max_det: -1 = the detector's
+        default cap, None = uncapped (the exact re-run after an overflow)."""
+        out = self.det.raw_batch(frames) if max_det == -1 else self.det.raw_batch(frames, max_det=max_det)
+        return out if len(out) == 3 else (out[0], out[1], None)
 
     def crops(self, frames, dets, counts):
         """Device-side B7 + crop arithmetic -> (items, info, n_faces tensor)."""
@@ -85,16 +87,25 @@ class FacePipeline:
 
     # -- whole step ------------------------------------------------------------------------------
     def step(self, frames):
-        """One pass over a batch of frames.  Returns dict(n_faces, info, emb, best, arg, keep)."""
-        dets, counts = self.detect(frames)
+        """One pass over a batch of frames.  Returns dict(n_faces, info, emb, best, arg, keep).
+        ``emb`` is a copy (the embedder's output lives in its plan arena and the next step overwrites it)."""
+        dets, counts, over = self.detect(frames)
         items, info, nf = self.crops(frames, dets, counts)
-        n = int(nf.item())                      # the one host sync of the step
+        # the one host sync of the step: the face count (sizes the embedder batch) and the detector's overflow flag
+        if over is None:
+            n, n_over = int(nf.item()), 0
+        else:
+            n, n_over = torch.stack([nf[0], over.sum().to(torch.int32)]).tolist()
+        if n_over:                              # > MAX_DET survivors in some frame: exact re-run without a cap
+            dets, counts, _ = self.detect(frames, max_det=None)
+            items, info, nf = self.crops(frames, dets, counts)
+            n = int(nf.item())
         cap = items.shape[0]
         if n > cap:
             raise L.FacepathError(f"{n} faces in the batch exceed max_faces_per_frame*B = {cap}")
         emb = self.embed(frames, items, n)
         res = self.filter(emb)
-        out = dict(n_faces=n, info=info[:n], emb=emb)
+        out = dict(n_faces=n, info=info[:n], emb=emb.clone(), items=items[:n])
         if res is not None:
             out.update(best=res[0], arg=res[1], keep=res[2])
         return out

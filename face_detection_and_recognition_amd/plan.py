@@ -309,6 +309,41 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * G + opix * G + opix * G + opix * cout))
         return out
 
+    def ystem(self, x, w1, scale1, bias1, w2, scale2, bias2, a_out, pool_out):
+        """Head of YOLOv5-face's StemBlock (common.py:58-73) as ONE op: stem_1 (3x3 s2 p1, SiLU) stays in LDS,
+        stem_2a (1x1, SiLU) -> a_out, maxpool2x2(stem_1) -> pool_out (a channel slice of stem_3's concat buffer).
+        scale1 / scale2 = None when the BatchNorm is folded into the conv (Model.fuse())."""
+        c1, c2 = w1.shape[0], w2.shape[0]
+        assert x.C == 4 and x.buf.ld == 4 and x.coff == 0
+        assert w1.shape[2:] == (3, 3) and w2.shape[1] == c1 and w2.shape[2:] == (1, 1)
+        assert c1 <= 32 and a_out.C <= 32 and pool_out.C >= c1 and pool_out.cmul == 1 and a_out.cmul == 1
+        H1, W1 = x.H // 2, x.W // 2
+        assert x.H % 4 == 0 and x.W % 4 == 0 and (a_out.H, a_out.W) == (H1, W1) and (pool_out.H, pool_out.W) == (H1 // 2, W1 // 2)
+        op = self._base(L.OP_YSTEM, x, a_out, H1, W1)
+        op.Cout = a_out.C
+        op.KH = op.KW = 3
+        op.stride = 2
+        op.pad_t = op.pad_l = 1
+        op.act = L.ACT_SILU
+        op.res_ld, op.res_ns = pool_out.buf.ld, pool_out.buf.ns
+        op.res_off = pool_out.buf.off + pool_out.coff
+        op.res_C = cpad(c1)
+        op.res_H, op.res_W = pool_out.H, pool_out.W
+        op.w_off = self.add_weight(pack_conv_weight(w1, 4, cpad(c1)))
+        if scale1 is not None:
+            op.scale_off = self.add_weight(pad_vec(scale1, 32, 0.0))
+        op.bias_off = self.add_weight(pad_vec(bias1, 32, 0.0))
+        nb2 = (a_out.C + 15) // 16
+        wq = np.zeros((32, nb2 * 16), np.float32)                       # [k][n], zero padded
+        wq[:c1, :c2] = np.asarray(w2, np.float32).reshape(c2, c1).T
+        blob = [np.ascontiguousarray(wq.reshape(2, 4, 4, nb2 * 16).transpose(0, 1, 3, 2)).reshape(-1),  # [j][g][n][e]
+                pad_vec(scale2 if scale2 is not None else np.ones(c2, np.float32), nb2 * 16, 0.0),
+                pad_vec(bias2, nb2 * 16, 0.0)]
+        op.slope_off = self.add_weight(np.concatenate(blob))
+        self.ops.append(op)
+        self.alg_bytes.append(4 * self.N * (x.H * x.W * 3 + H1 * W1 * c1 + H1 * W1 * c1 + H1 * W1 * c2))
+        return a_out
+
     def maxpool(self, x, out, k, stride, pad):
         assert out.C == x.C
         op = self._base(L.OP_MAXPOOL, x, out, out.H, out.W)
@@ -348,10 +383,57 @@ class PlanBuilder:
         return self.ops, weights, self.peak
 
 
-class CompiledPlan:
-    """Ops + device weights + arena, ready to run on a stream."""
+class PlanCache:
+    """Per-network cache of compiled plans, keyed by batch shape.
 
-    def __init__(self, builder, device):
+    * LRU-bounded (``max_plans``): a plan owns an activation arena of several GB at batch >= 1024, so a caller whose
+      batch size varies (FacePipeline's 64-row buckets) must not pin one arena per size it has ever seen.
+    * The packed weight blob does not depend on the batch size: every plan of one network shares ONE device copy
+      (compared by content on the host, so a plan emitted with different fusion switches gets its own).
+    ``clear()`` is what load_state_dict / .to() / fuse() call."""
+
+    def __init__(self, max_plans=4):
+        self.max_plans = int(max_plans)
+        self._plans = {}          # insertion-ordered: oldest first
+        self._weights = []        # [(host ndarray, device tensor)]
+
+    def clear(self):
+        self._plans = {}
+        self._weights = []
+
+    def __len__(self):
+        return len(self._plans)
+
+    def __contains__(self, key):
+        return key in self._plans
+
+    def get(self, key, build):
+        plan = self._plans.pop(key, None)
+        if plan is None:
+            while len(self._plans) >= self.max_plans:
+                self._plans.pop(next(iter(self._plans)))
+            plan = build(self)
+        self._plans[key] = plan   # most recently used last
+        return plan
+
+    def device_weights(self, host, device):
+        import torch
+        for h, d in self._weights:
+            if d.device == device and h.shape == host.shape and np.array_equal(h, host):
+                return d
+        d = torch.from_numpy(host).to(device)
+        self._weights.append((host, d))
+        return d
+
+
+class CompiledPlan:
+    """Ops + device weights + arena, ready to run on a stream.
+
+    Every tensor a plan exposes (``input``, ``out``, ``r``, ``c``, ``z`` ...) is a VIEW into its arena: the next
+    ``run()`` of the same plan overwrites it.  The public forward APIs of the networks return clones; the
+    ``*_resident`` variants hand out the views (zero-copy, for callers that consume them before the next run)."""
+
+    def __init__(self, builder, device, cache=None):
         import torch
         ops, weights, arena_floats = builder.finish()
         self.n_ops = len(ops)
@@ -359,7 +441,8 @@ class CompiledPlan:
         assert len(self.alg_bytes) == self.n_ops
         self.ops = (L.FpOp * max(self.n_ops, 1))(*ops)
         self.device = torch.device(device)
-        self.weights = torch.from_numpy(weights).to(self.device)
+        self.weights = cache.device_weights(weights, self.device) if cache is not None else \
+            torch.from_numpy(weights).to(self.device)
         self.arena_floats = int(arena_floats)
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=self.device)
         self.lib = L.load()

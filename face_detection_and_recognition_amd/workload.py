@@ -23,6 +23,8 @@ from .modules.mobile_facenet.mobile_facenet import MobileFaceNet
 from .synth import synth_state_dict
 
 FRAME_H, FRAME_W = 576, 1024
+BOX_PX = 165.0     # synthetic BlazeFace box size in model-input pixels (tools/calibrate_workload.py picks the value that
+                   # gives ~2 faces per frame after the weighted NMS)
 
 
 def make_frames(B, device, seed=1234, h=FRAME_H, w=FRAME_W):
@@ -46,7 +48,7 @@ def make_frames(B, device, seed=1234, h=FRAME_H, w=FRAME_W):
     return out
 
 
-def build_blazeface_back(device, seed=101, box_px=90.0):
+def build_blazeface_back(device, seed=101, box_px=BOX_PX):
     net = BlazeFace(back_model=True)
     sd = synth_state_dict(net.state_dict(), seed, residual_gain=0.5)
     # well-formed boxes: small random offsets around the anchor, positive w/h of ~box_px (model-input pixels)
@@ -81,15 +83,69 @@ def calibrate_scores(model, frames, cand_per_frame=64):
     with torch.no_grad():
         net.classifier_8.bias += delta
         net.classifier_16.bias += delta
-    net._plans = {}
+    net._plans.clear()
     return delta
 
 
-def build_detector(device, calib_frames, cand_per_frame=64, det_thres=0.70, bbox_area_thres=0.12):
-    net = build_blazeface_back(device)
+def build_detector(device, calib_frames, cand_per_frame=64, det_thres=0.70, bbox_area_thres=0.12, box_px=BOX_PX):
+    net = build_blazeface_back(device, box_px=box_px)
     model = BlazeFaceModel("", det_thres, bbox_area_thres, "back", device=str(device), net=net)
     calibrate_scores(model, calib_frames, cand_per_frame)
     return model
+
+
+def build_yolo_detector(device, calib_frames, name="yolov5s", cand_per_frame=80, det_thres=0.4, bbox_area_thres=0.12,
+                        input_size=(640, 640), seed=11, box_gain=2.0, obj_spread=2.0):
+    """YOLOV5FaceModel with seeded synthetic weights for BASELINE configs [2] / [3].  Random weights give arbitrary
+    objectness, so -- as for BlazeFace -- the Detect biases are conditioned once, off the clock: the class
+    score saturates (nc = 1), boxes are a few anchors wide (``box_gain`` raises the raw w/h logits), and the objectness
+    bias is shifted so that ~``cand_per_frame`` of the 25 200 rows pass conf 0.4 per frame before NMS."""
+    from .modules.yolov5_face import inference_pytorch_model_yolov5_face, preprocess_batch
+    from .modules.yolov5_face.model import YOLOV5FaceModel
+    from .modules.yolov5_face.yolo import Model
+    m = Model(name)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+    m = m.fuse().to(device)
+    det = m.model[-1]
+    with torch.no_grad():
+        for conv in det.m:
+            conv.bias.view(det.na, det.no)[:, 15] += 8.0
+            conv.bias.view(det.na, det.no)[:, 2:4] += box_gain
+    m._plans.clear()
+    in_w, in_h = input_size
+
+    def obj_logits():
+        m._plans.clear()
+        z = m.run_plan(preprocess_batch(m, calib_frames, input_size))
+        obj = z[..., 4].clamp(1e-7, 1 - 1e-7)
+        return torch.log(obj / (1 - obj))                      # (B, rows), rows ordered (level, anchor, y, x)
+
+    # random weights leave the objectness logit almost constant over the image (std ~0.01) and offset per (level,
+    # anchor) by the random bias: normalise every (level, anchor) group to the same mean and a spread of ~obj_spread so
+    # that candidates come from every level / anchor and follow the image content ...
+    logit = obj_logits()
+    row = 0
+    with torch.no_grad():
+        for lvl, conv in enumerate(det.m):
+            npos = (in_h // int(det.stride[lvl])) * (in_w // int(det.stride[lvl]))
+            for a in range(det.na):
+                grp = logit[:, row:row + npos]
+                mu, sd = float(grp.mean()), float(grp.std())
+                g = obj_spread / max(sd, 1e-6)
+                conv.weight.view(det.na, det.no, -1)[a, 4] *= g
+                b = conv.bias.view(det.na, det.no)
+                b[a, 4] = g * (b[a, 4] - mu)                   # group mean -> 0
+                row += npos
+    # ... then shift it so that ~cand_per_frame rows per frame pass conf 0.4
+    logit = obj_logits().flatten()
+    k = min(int(cand_per_frame * calib_frames.shape[0]), logit.numel() - 1)
+    kth = torch.topk(logit, k + 1).values[-1]
+    delta = math.log(0.4 / 0.6) - float(kth) + 1e-3
+    with torch.no_grad():
+        for conv in det.m:
+            conv.bias.view(det.na, det.no)[:, 4] += delta
+    m._plans.clear()
+    return YOLOV5FaceModel(m, det_thres, bbox_area_thres, inference_pytorch_model_yolov5_face, input_size)
 
 
 def build_embedder(device, seed=300):

@@ -56,7 +56,9 @@ enum fp_op_kind {
   FP_OP_COPY = 5,       /* channel-slice copy (concat / chunk / shuffle interleave) */
   FP_OP_L2NORM = 6,     /* out[m,:] = in[m,:] / ||in[m,:]||_2 over Cin channels (mobile_facenet.py:30-33) */
   FP_OP_BLAZEBLOCK = 7, /* fused BlazeBlock: dw3x3 -> 1x1 -> (+shortcut) -> ReLU (blazeface.py:12-47) */
-  FP_OP_DWPW = 8        /* fused Depth_Wise tail: dw3x3(+BN,+PReLU) -> 1x1(+BN) [+x] (mobile_facenet.py:72-85) */
+  FP_OP_DWPW = 8,       /* fused Depth_Wise tail: dw3x3(+BN,+PReLU) -> 1x1(+BN) [+x] (mobile_facenet.py:72-85) */
+  FP_OP_YSTEM = 9       /* head of YOLOv5-face's StemBlock (y5/models/common.py:58-73): stem_1 (3x3 s2, SiLU) kept in LDS ->
+                           stem_2a (1x1, SiLU) -> out, and maxpool2x2(stem_1) -> res view (the concat half stem_3 reads) */
 };
 
 enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
@@ -112,6 +114,12 @@ typedef struct fp_op {
  *            bias_off  -> optional [roundup(Cout,4)] PReLU slopes applied to the 1x1 output (a depthwise Conv_block
  *            followed by a 1x1 Conv_block, mobile_facenet.py:117-118,70); not combined with a residual.
  *   BLAZEBLOCK : w_off -> [9][Cin] taps, scale_off -> [Cin] depthwise bias, slope_off -> packed 1x1, bias_off -> [Cout]
+ *   YSTEM  : in = the 4-float-pixel image (Cin = in_ld = 4), H and W multiples of 4; OH x OW = H/2 x W/2 (stem_1 / stem_2a
+ *            map), Cout = stem_2a's physical channels (<= 32); the res_* view receives maxpool2x2(stem_1):
+ *            res_C = stem_1's physical channels (<= 32), res_H x res_W = OH/2 x OW/2.
+ *            w_off -> stem_1 packed as CONV (K = 36 -> 40, Npad = 32), scale_off (-1 = none) / bias_off -> [32];
+ *            slope_off -> stem_2a: [2][4][NB2*16][4] with element e of (j, g, n) = W[n][16j + 4g + e] (NB2 =
+ *            ceil(Cout/16), zero padded), then [NB2*16] scale, [NB2*16] bias.  Both convs end in SiLU.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */
@@ -180,8 +188,9 @@ int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int fr
  * Then scale_coords/clip/round (fde/modules/utils/image.py:62-99) and the crop arithmetic of
  * fde/face_extraction/extract_faces_from_dataset.py:289-303 (int(), offsets, clamp).  gain/pad are
  * scale_coords' values computed by the caller.  items[max_faces], face_info[max_faces][7] =
- * (frame, x1, y1, x2, y2 in original-frame pixels (rounded), conf, bbox area fraction of the model input as
- * inference.py:37-44 reports it), n_faces[1] = total found (the caller
+ * (frame, x1, y1, x2, y2 in original-frame pixels (rounded), conf, bbox area: fmt 0 the FRACTION of the model input
+ * as inference.py:40-46 reports it (filter 100*(area/total) > thr); fmt 1 the PERCENT (100*area)/total as
+ * onnx_utils.py:329-332 computes, compares and returns it), n_faces[1] = total found (the caller
  * must check n_faces <= max_faces).  Faces are ordered by (frame, detection).
  */
 int fp_dets_to_crops(const float* dets, const int32_t* counts, int B, int max_dets, int row_floats, int fmt,

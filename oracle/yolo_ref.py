@@ -227,3 +227,21 @@ def w_non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.4):
             det = det[1:][ious < nms_thres]
         output.append(torch.cat(keep))
     return output
+
+
+def get_bboxes_confs_areas(dets, det_thres, bbox_area_thres, orig_size, in_size):
+    """get_bboxes_confs_areas (fde/modules/yolov5_face/onnx/onnx_utils.py:313-340), numpy, same operation order:
+    conf > det_thres; perc = 100 * area / (iw * ih) (the PERCENT, computed in the dets' dtype); perc > bbox_area_thres;
+    scale_coords + round.  As in the reference the returned perc is NOT filtered by the area test (it has one entry
+    per detection that passed the confidence test).  Pinned by tests/golden/yolo_bboxes_confs_areas.npz."""
+    from .image_ref import scale_coords
+    w, h = orig_size
+    iw, ih = in_size
+    dets = np.asarray(dets)
+    dets = dets[dets[..., 4] > det_thres]
+    total_area = iw * ih
+    bbox_area = (dets[:, 2] - dets[:, 0]) * (dets[:, 3] - dets[:, 1])
+    bbox_area_perc = 100 * bbox_area / total_area
+    dets = dets[bbox_area_perc > bbox_area_thres]
+    boxes = scale_coords((ih, iw), dets[..., :4].copy(), (h, w)).round()
+    return boxes, dets[..., 4], bbox_area_perc

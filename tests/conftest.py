@@ -18,6 +18,12 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
+def rel_err(a, b):
+    """max |a - b| relative to the scale of b."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
 @pytest.fixture(scope="session")
 def lib():
     from face_detection_and_recognition_amd import _lib

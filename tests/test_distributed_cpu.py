@@ -44,6 +44,40 @@ def _worker(rank, world, port, q):
         np.array_equal(keep.numpy(), rk[g0:g1])
     rows, offs = D.all_gather_rows(torch.from_numpy(R[r0:r1]))
     ok = ok and np.array_equal(rows.numpy(), R) and offs[-1] == len(R)
+    # equal-size reference blocks (BASELINE configs[4]): one all_gather_into_tensor, no size exchange
+    Re = R[:36]
+    e0, e1 = rank * 18, rank * 18 + 18
+    b2, a2, k2 = D.sharded_cosine_filter(torch.from_numpy(G[g0:g1]), torch.from_numpy(Re[e0:e1]), 0.1, filter_fn,
+                                         equal_blocks=True)
+    rb2, ra2, rk2, _ = similarity_ref.cosine_filter(G, Re, 0.1)
+    ok = ok and np.allclose(b2.numpy(), rb2[g0:g1], atol=1e-6) and np.array_equal(a2.numpy(), ra2[g0:g1])
+    # the step exchange of bench.py: fixed-capacity blocks + device-side counts, each rank's faces against the OTHER
+    # ranks' faces (own and padding rows masked by a zero inverse norm)
+    cap, D_ = 24, 64
+    n_loc = [17, 9][rank]
+    E_all = [rng.normal(0, 1, (n, D_)).astype(np.float32) for n in (17, 9)]
+    block = np.zeros((cap, D_), np.float32)
+    block[:n_loc] = E_all[rank]
+    block[n_loc:] = 7.0                                      # junk in the padding rows must not matter
+
+    def filter_rinv(g, r, tau, rinv):
+        gn = g.numpy() / np.maximum(np.linalg.norm(g.numpy(), axis=1, keepdims=True), 1e-30)
+        s = gn @ (r.numpy() * rinv.numpy()[:, None]).T
+        return torch.from_numpy(s.max(1)), torch.from_numpy(s.argmax(1).astype(np.int32)), torch.from_numpy(s.max(1) >= tau)
+
+    def inv_norm(r):
+        return 1.0 / torch.linalg.norm(r, dim=1).clamp_min(1e-30)
+
+    best3, arg3, keep3, counts = D.cross_rank_match(torch.from_numpy(block), torch.tensor([n_loc]), 0.1, filter_rinv,
+                                                    inv_norm)
+    other = E_all[1 - rank]
+    mine = E_all[rank]
+    sref = (mine / np.linalg.norm(mine, axis=1, keepdims=True)) @ (other / np.linalg.norm(other, axis=1, keepdims=True)).T
+    ok = ok and counts.tolist() == [17, 9]
+    ok = ok and np.allclose(best3.numpy()[:n_loc], sref.max(1), atol=1e-5)
+    ok = ok and np.array_equal(arg3.numpy()[:n_loc], (1 - rank) * cap + sref.argmax(1))
+    rows_g, valid_g, _ = D.all_gather_blocks(torch.from_numpy(block), torch.tensor([n_loc]))
+    ok = ok and valid_g.tolist() == [i < 17 for i in range(cap)] + [i < 9 for i in range(cap)]
     mean = D.sharded_l2_mean(torch.from_numpy(R[r0:r1]))
     ok = ok and np.allclose(mean.numpy(), R.mean(0), atol=1e-6)
     q.put((rank, bool(ok)))

@@ -12,6 +12,7 @@ from face_detection_and_recognition_amd.modules.blazeface.blazeface import gener
 from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import MobileFaceNet
 from face_detection_and_recognition_amd.modules.utils.inference import get_dets_bboxes_confs_lmarks_areas
 from face_detection_and_recognition_amd.synth import synth_state_dict
+from conftest import rel_err
 from oracle import blazeface_ref, image_ref, mobilefacenet_ref, similarity_ref
 
 pytestmark = pytest.mark.gpu
@@ -48,6 +49,51 @@ def test_detect_face_blazeface_cli_matches_oracle(dev, tmp_path):
         detect_face_blazeface.main(["-i", ipath, "--md", str(tmp_path / "x.tflite"), "-d", "hip"])
     with pytest.raises(FileNotFoundError):
         detect_face_blazeface.main(["-i", str(tmp_path / "missing.jpg"), "--md", wpath, "-d", "hip"])
+
+
+def test_detect_face_blazeface_cli_front_camera(dev, tmp_path):
+    """BASELINE configs[0]: detect_face_blazeface.py --mt front on one 576x1024 image (128x128 front-camera network,
+    threshold 0.75), against the oracle's reference flow on the decoded file."""
+    from face_detection_and_recognition_amd import detect_face_blazeface
+    from face_detection_and_recognition_amd.modules.blazeface.blazeface import BlazeFace
+    from face_detection_and_recognition_amd.modules.utils.inference import load_image
+    frames = W.make_frames(4, dev, seed=21)
+    net = BlazeFace(back_model=False)
+    sd = synth_state_dict(net.state_dict(), 111, residual_gain=0.5)
+    for name in ("regressor_8", "regressor_16"):            # well-formed boxes of ~40 input pixels (SURVEY F8)
+        sd[name + ".weight"] = sd[name + ".weight"] * 0.05
+        b = sd[name + ".bias"] * 0.0
+        b.view(-1, 16)[:, 2:4] = 40.0
+        sd[name + ".bias"] = b
+    for name in ("classifier_8", "classifier_16"):
+        sd[name + ".weight"] = sd[name + ".weight"].abs() * 0.5
+        sd[name + ".bias"] = sd[name + ".bias"] * 0.0
+    # shift the classifier bias so ~40 of the 896 anchors reach the front model's 0.75 threshold (oracle forward)
+    ipath = str(tmp_path / "frame.jpg")
+    _save_png_as_jpg_free(ipath, frames[0].cpu().numpy())
+    img = load_image(ipath)
+    assert img.shape == (576, 1024, 3)
+    lb = image_ref.pad_resize_image(img, (128, 128))[..., ::-1].copy()
+    x_u8 = torch.from_numpy(lb).permute(2, 0, 1).unsqueeze(0)
+    anchors = torch.from_numpy(generate_anchors(False))
+    with torch.no_grad():
+        _, c = blazeface_ref.forward(sd, x_u8.float() / 127.5 - 1.0, False)
+    kth = torch.sort(c.flatten(), descending=True)[0][40]
+    delta = float(np.log(0.75 / 0.25) - kth) + 0.01
+    for name in ("classifier_8", "classifier_16"):
+        sd[name + ".bias"] = sd[name + ".bias"] + delta
+    wpath = str(tmp_path / "blazeface.pth")
+    torch.save(sd, wpath)
+    np.save(str(tmp_path / "anchors.npy"), generate_anchors(False))
+    post = detect_face_blazeface.main(["-i", ipath, "--md", wpath, "--mt", "front", "--dt", "0.7", "--at", "0.12",
+                                       "-d", "hip:0"])
+    faces, _ = blazeface_ref.predict_on_batch(sd, x_u8, anchors, False)
+    d = faces[0].numpy()[:, [1, 0, 3, 2] + list(range(4, 17))]
+    ref = image_ref.dets_to_boxes(d.copy(), (img.shape[1], img.shape[0]), (128, 128), 0.7, 0.12)
+    assert len(post.boxes) == len(ref["boxes"]) > 0
+    assert np.abs(post.boxes - ref["boxes"]).max() <= 1.0          # rounded pixel coordinates
+    np.testing.assert_allclose(post.bbox_confs, ref["bbox_confs"], atol=1e-4)
+    np.testing.assert_allclose(post.bbox_areas, ref["bbox_areas"], rtol=1e-4)
 
 
 def test_filter_faces_using_reference_cli(dev, tmp_path):
@@ -157,6 +203,75 @@ def test_extract_faces_batched_matches_oracle_and_format(dev, tmp_path):
     assert total == sum(len(r.confs) for r in recs)
     assert a["media_id"] == "vid0" and a["label"] == 7 and len(a["frames_info"]) == 6
     assert a["feature"].shape == (X.MAX_N_FRAME_FROM_VID * X.MAX_N_FACES_PER_FRAME * 512,) and a["feature"].dtype == np.float32
+
+
+def test_yolov5s_to_mobilefacenet_pipeline_matches_oracle(dev):
+    """BASELINE configs[3]: YOLOv5s-face detect -> crops -> Mobile-FaceNet, the reference's own composition
+    (fde/face_extraction/extract_faces_from_dataset.py:270-307 with bbox_conf_area_func = get_bboxes_confs_areas,
+    fde/modules/yolov5_face/onnx/onnx_utils.py:313-340) through FacePipeline on 576x1024 frames.
+      * forward: the HIP decoded predictions against the oracle network, within tolerance;
+      * NMS kept rows, filtered boxes and the fmt = 1 crop rectangles: exact, with the oracle post-processing run on
+        the SAME decoded predictions (so the comparison is bit-for-bit, not blurred by the forward tolerance);
+      * embeddings: <= 1e-4 against the oracle Mobile-FaceNet on the oracle's crops."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import preprocess_batch
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import SPECS
+    from face_detection_and_recognition_amd.pipeline import FacePipeline
+    from oracle import yolo_ref
+    B = 4
+    frames = W.make_frames(B, dev, seed=31)
+    det = W.build_yolo_detector(dev, W.make_frames(4, dev, seed=32), "yolov5s", cand_per_frame=80)
+    emb = W.build_embedder(dev)
+    ref = W.make_reference(64, dev)
+    pipe = FacePipeline(det, emb, ref, tau=0.0, max_faces_per_frame=64)
+    out = pipe.step(frames)
+    torch.cuda.synchronize()
+    n = out["n_faces"]
+    assert n >= B, "workload calibration found too few faces"
+    info, items, got_emb = out["info"].cpu().numpy(), out["items"].cpu().numpy(), out["emb"].cpu().numpy()
+
+    # the decoded predictions the device NMS consumed (same plan, same input)
+    plan = preprocess_batch(det.net, frames, det.input_size)
+    z = det.net.run_plan(plan).clone().cpu()
+    fr = frames.cpu().numpy()
+    sd_det = {k: v.detach().cpu() for k, v in det.net.state_dict().items()}
+    sd_emb = {k: v.detach().cpu() for k, v in emb.state_dict().items()}
+    lb = image_ref.pad_resize_image(fr[0][..., ::-1], (640, 640))
+    x0 = torch.from_numpy(image_ref.yolo_lut()[lb]).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        z_ref, _ = yolo_ref.forward(SPECS["yolov5s"], sd_det, x0)
+    assert rel_err(z[0].numpy(), z_ref[0].numpy()) < 1e-4
+
+    kept, _ = yolo_ref.non_max_suppression_face(z.numpy(), 0.4, 0.5)
+    row = 0
+    embs = []
+    for i in range(B):
+        boxes, confs, areas = yolo_ref.get_bboxes_confs_areas(kept[i].numpy(), det.det_thres, det.bbox_area_thres,
+                                                              (1024, 576), (640, 640))
+        areas = areas[areas > det.bbox_area_thres]
+        k = len(boxes)
+        np.testing.assert_array_equal(info[row:row + k, 0], i)
+        np.testing.assert_array_equal(info[row:row + k, 1:5], boxes)               # kept + filtered boxes, exact
+        np.testing.assert_array_equal(info[row:row + k, 5], confs)
+        np.testing.assert_array_equal(info[row:row + k, 6], areas)                 # percent, as the reference returns
+        for j, box in enumerate(boxes):
+            crop, (x, y, xw, yh) = image_ref.crop_face(fr[i], box)
+            assert tuple(items[row + j, :5]) == (i, x, y, xw - x, yh - y)          # fmt = 1 crop rectangle, exact
+            face = image_ref.mfn_lut()[image_ref.resize_bilinear_u8(crop, (112, 112))]
+            xin = torch.from_numpy(np.ascontiguousarray(face.transpose(2, 0, 1))).unsqueeze(0)
+            with torch.no_grad():
+                embs.append(mobilefacenet_ref.forward(sd_emb, xin)[0].numpy())
+        row += k
+    assert row == n
+    assert np.abs(got_emb - np.stack(embs)).max() < 1e-4
+    # plugin API on the same detector: (k, 5) rows normalised to the input size (yolov5_face/model.py:23-37)
+    d5 = det(fr[0])
+    assert d5.shape == (len(kept[0]), 5)
+    np.testing.assert_allclose(d5[:, :4] * 640, kept[0].numpy()[:, :4], rtol=0, atol=1e-3)
+    # results of one step survive the next one (ADVICE r1: outputs used to alias the plan arena)
+    e0 = out["emb"].clone()
+    pipe.step(W.make_frames(B, dev, seed=33))
+    torch.cuda.synchronize()
+    assert torch.equal(e0, out["emb"])
 
 
 @pytest.mark.parametrize("tag,kind,batched", [("l2", "MOBILE_FACENET", True), ("cos", "FACE_REID_MNV3", True),

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import golden, rel_err
 from face_detection_and_recognition_amd import _lib as L
 from face_detection_and_recognition_amd import similarity as S
 from face_detection_and_recognition_amd.modules.blazeface.blazeface import (BlazeBlock, BlazeFace, FinalBlazeBlock,
@@ -16,11 +16,6 @@ from face_detection_and_recognition_amd.synth import synth_state_dict
 from oracle import blazeface_ref, image_ref, mobilefacenet_ref, similarity_ref
 
 pytestmark = pytest.mark.gpu
-
-
-def rel_err(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
 def run_block(block, x_nchw, dev, out_hw, cout):
@@ -408,7 +403,7 @@ def _yolo(name, dev, seed, fuse):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("name", ["yolov5n", "yolov5s"])
+@pytest.mark.parametrize("name", ["yolov5n", "yolov5s", "yolov5n-0.5"])
 @pytest.mark.parametrize("fuse", [True, False])
 def test_yolo_forward_vs_reference_golden(dev, name, fuse):
     g = golden(f"{name}_forward")
@@ -418,6 +413,129 @@ def test_yolo_forward_vs_reference_golden(dev, name, fuse):
     for i, h in enumerate(heads):
         assert rel_err(h.cpu().numpy(), g[f"head{i}"]) < 1e-4
     assert rel_err(z.cpu().numpy(), g["z"]) < 1e-4
+
+
+def _run_yolo_block(block, x_nchw, dev):
+    """One emit()-able YOLOv5-face block on an NCHW numpy input -> NCHW numpy (all logical output channels)."""
+    N, C, H, W = x_nchw.shape
+    pb = PlanBuilder(N)
+    inp = pb.new_buf(H, W, C)
+    y = block.emit(pb, inp.view())
+    plan = CompiledPlan(pb, dev)
+    t = plan.buf_tensor(inp, N)
+    t.zero_()
+    t[..., :C].copy_(torch.from_numpy(x_nchw).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    return plan.buf_tensor(y.buf, N)[..., y.coff:y.coff + y.C].permute(0, 3, 1, 2).cpu().numpy()
+
+
+_YOLO_BLOCKS = {
+    "conv": lambda Y: Y.Conv(16, 32, 3, 2), "conv1x1": lambda Y: Y.Conv(24, 40, 1, 1),
+    "stem": lambda Y: Y.StemBlock(3, 32, 3, 2), "shuffle_s2": lambda Y: Y.ShuffleV2Block(32, 128, 2),
+    "shuffle_s1": lambda Y: Y.ShuffleV2Block(128, 128, 1), "c3": lambda Y: Y.C3(64, 64, 2),
+    "c3_noshortcut": lambda Y: Y.C3(96, 64, 1, False), "spp": lambda Y: Y.SPP(128, 128, (3, 5, 7)),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(_YOLO_BLOCKS))
+def test_yolo_block_vs_reference_golden(dev, tag):
+    """each YOLOv5-face block on the HIP path against the reference's own module output
+    (tests/golden/yolo_blocks.npz; Conv also after fuse_conv_and_bn)."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    g = golden("yolo_blocks")
+    blk = _YOLO_BLOCKS[tag](Y)
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), int(g[f"{tag}_seed"])))
+    want = g[f"{tag}_y"]
+    got = _run_yolo_block(blk.to(dev), g[f"{tag}_x"], dev)[:, :want.shape[1]]
+    assert rel_err(got, want) < 1e-5, tag
+    if tag == "conv":
+        blk.fuse()
+        got = _run_yolo_block(blk, g["conv_x"], dev)[:, :want.shape[1]]
+        assert rel_err(got, g["conv_y_fused"]) < 1e-5
+
+
+@pytest.mark.parametrize("c,hw,fuse_bn", [(32, (72, 88), False), (24, (40, 136), True), (16, (64, 64), True)])
+def test_yolo_stem_fused_kernel_matches_unfused_ops(dev, c, hw, fuse_bn):
+    """FP_OP_YSTEM (stem_1 -> LDS -> stem_2a + maxpool, csrc/ystem.hip) against the five separate ops on ragged maps
+    (tiles of 8 x 32 stem_1 pixels that overhang the map), live and folded BatchNorm, c = 32 / 24 / 16."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    from oracle import yolo_ref
+    rng = np.random.default_rng(c)
+    blk = Y.StemBlock(3, c, 3, 2)
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), 700 + c))
+    if fuse_bn:
+        for m in (blk.stem_1, blk.stem_2a, blk.stem_2b, blk.stem_3):
+            m.fuse()
+    blk = blk.to(dev)
+    x = rng.uniform(-1, 1, (3, 3) + hw).astype(np.float32)
+    outs = {}
+    for flag in (True, False):
+        Y.StemBlock.FUSE = flag
+        try:
+            outs[flag] = _run_yolo_block(blk, x, dev)[:, :c]
+        finally:
+            Y.StemBlock.FUSE = True
+    with torch.no_grad():
+        want = yolo_ref._stem({k: v.cpu() for k, v in blk.state_dict().items()}, "", torch.from_numpy(x)).numpy()
+    assert rel_err(outs[True], want) < 1e-5 and rel_err(outs[False], want) < 1e-5
+    assert rel_err(outs[True], outs[False]) < 2e-6
+
+
+def test_yolo_concat_in_place_matches_copies(dev):
+    """Concat inputs produced straight into the concat buffer (Model._emit) vs explicit copies: identical outputs."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    g = golden("yolov5s_forward")
+    zs = {}
+    for flag in (True, False):
+        Y.Model.CONCAT_IN_PLACE = flag
+        try:
+            m = _yolo("yolov5s", dev, int(g["seed"]), True)
+            n_copy = sum(1 for op in m._emit(1, 128, 128)[0].ops if op.kind == L.OP_COPY)
+            assert n_copy == (0 if flag else 8)
+            zs[flag] = m(torch.from_numpy(g["x"]))[0].cpu().numpy()
+        finally:
+            Y.Model.CONCAT_IN_PLACE = True
+    np.testing.assert_array_equal(zs[True], zs[False])
+
+
+def test_dets_to_crops_yolo_rows_vs_reference_golden(dev, lib):
+    """fp_dets_to_crops fmt = 1 against get_bboxes_confs_areas run by the reference itself
+    (tests/golden/yolo_bboxes_confs_areas.npz): kept rows, rounded boxes and percent areas bit-exact; the crop
+    rectangles against the oracle's crop arithmetic (extract_faces_from_dataset.py:289-303)."""
+    from face_detection_and_recognition_amd import _lib as L
+    from face_detection_and_recognition_amd.pipeline import FACE_OFFSETS, scale_coords_params
+    g = golden("yolo_bboxes_confs_areas")
+    dets = g["dets"]
+    n = dets.shape[0]
+    # two images: the golden rows, and the same rows reversed (ordering by (frame, detection))
+    d = torch.from_numpy(np.stack([dets, dets[::-1].copy()])).to(dev)
+    counts = torch.tensor([n, n], dtype=torch.int32, device=dev)
+    cap = 2 * n
+    items = torch.empty((cap, 9), dtype=torch.int32, device=dev)
+    info = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    nf = torch.empty((1,), dtype=torch.int32, device=dev)
+    gain, px, py = scale_coords_params((640, 640), (1024, 576))
+    tx, ty, bx, by = FACE_OFFSETS
+    L.check(lib.fp_dets_to_crops(L.ptr(d), L.ptr(counts), 2, n, 16, 1, 640, 640, 1024, 576, 0.7, 0.12, float(gain),
+                                 float(px), float(py), tx, ty, bx, by, 112, 112, cap, L.ptr(items), L.ptr(info),
+                                 L.ptr(nf), L.current_stream(dev)), "fp_dets_to_crops")
+    torch.cuda.synchronize()
+    k = len(g["boxes"])
+    assert int(nf) == 2 * k and k > 0
+    info, items = info.cpu().numpy(), items.cpu().numpy()
+    conf_pass = dets[:, 4] > 0.7
+    areas_kept = g["areas"][g["areas"] > 0.12]                # the reference returns the unfiltered percent column
+    assert len(areas_kept) == k and conf_pass.sum() == len(g["areas"])
+    np.testing.assert_array_equal(info[:k, 0], 0)
+    np.testing.assert_array_equal(info[:k, 1:5], g["boxes"])
+    np.testing.assert_array_equal(info[:k, 5], g["confs"])
+    np.testing.assert_array_equal(info[:k, 6], areas_kept)
+    np.testing.assert_array_equal(info[k:2 * k, 1:5], g["boxes"][::-1])
+    frame = np.zeros((576, 1024, 3), np.uint8)
+    for i, box in enumerate(g["boxes"]):
+        _, (x, y, xw, yh) = image_ref.crop_face(frame, box)
+        assert tuple(items[i, :5]) == (0, x, y, xw - x, yh - y)
 
 
 def test_yolo_decode_and_wnms_vs_reference_golden(dev):
@@ -477,7 +595,7 @@ def test_yolo_pipeline_matches_oracle_end_to_end(dev):
         for conv in m.model[-1].m:
             conv.bias.view(3, 16)[:, 4] += delta
             conv.bias.view(3, 16)[:, 15] += 6.0
-    m._plans = {}
+    m._plans.clear()
     model = YOLOV5FaceModel(m, 0.4, 0.0, inference_pytorch_model_yolov5_face, (640, 640))
     dets = model(frame)
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}

@@ -4,7 +4,7 @@ This is what pins the oracle; the GPU parity tests then compare the HIP path wit
 import numpy as np
 import torch
 
-from conftest import golden
+from conftest import golden, rel_err
 from face_detection_and_recognition_amd.modules.blazeface.blazeface import BlazeFace
 from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import MobileFaceNet
 from face_detection_and_recognition_amd.synth import synth_state_dict
@@ -163,3 +163,58 @@ def test_triton_postprocess_oracle_decode_matches_reference_golden():
     up = ref.resize_bilinear_f32(img, (39, 27))
     assert up.shape == (27, 39, 3) and np.allclose(up[0, 0], img[0, 0]) and np.allclose(up[-1, -1], img[-1, -1])
     assert np.allclose(ref.resize_bilinear_f32(np.full((5, 7, 3), 3.5, np.float32), (112, 112)), 3.5)
+
+
+def test_yolo_blocks_oracle_vs_reference_golden():
+    """oracle/yolo_ref.py block restatements against the reference's own module classes (tests/golden/yolo_blocks.npz,
+    tools/gen_golden.py gen_yolo_blocks) and the yolov5n-0.5 whole net."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import SPECS
+    from oracle import yolo_ref
+    g = golden("yolo_blocks")
+    cases = {
+        "conv": (lambda: Y.Conv(16, 32, 3, 2), lambda sd, x: yolo_ref._conv(sd, "", x, 3, 2)),
+        "conv1x1": (lambda: Y.Conv(24, 40, 1, 1), lambda sd, x: yolo_ref._conv(sd, "", x, 1, 1)),
+        "stem": (lambda: Y.StemBlock(3, 32, 3, 2), lambda sd, x: yolo_ref._stem(sd, "", x)),
+        "shuffle_s2": (lambda: Y.ShuffleV2Block(32, 128, 2), lambda sd, x: yolo_ref._shuffle_block(sd, "", x, 2)),
+        "shuffle_s1": (lambda: Y.ShuffleV2Block(128, 128, 1), lambda sd, x: yolo_ref._shuffle_block(sd, "", x, 1)),
+        "c3": (lambda: Y.C3(64, 64, 2), lambda sd, x: yolo_ref._c3(sd, "", x, 2, True)),
+        "c3_noshortcut": (lambda: Y.C3(96, 64, 1, False), lambda sd, x: yolo_ref._c3(sd, "", x, 1, False)),
+        "spp": (lambda: Y.SPP(128, 128, (3, 5, 7)), lambda sd, x: yolo_ref._spp(sd, "", x, (3, 5, 7))),
+    }
+    for tag, (ctor, fn) in cases.items():
+        mod = ctor()
+        sd = synth_state_dict(mod.state_dict(), int(g[f"{tag}_seed"]))     # same keys as the reference module
+        with torch.no_grad():
+            y = fn(sd, torch.from_numpy(g[f"{tag}_x"]))
+        assert rel_err(y.numpy(), g[f"{tag}_y"]) < 2e-6, tag
+    # Conv after fuse_conv_and_bn (utils/torch_utils.py:164-184): this package's fuse() against the reference's output
+    mod = Y.Conv(16, 32, 3, 2)
+    mod.load_state_dict(synth_state_dict(mod.state_dict(), int(g["conv_seed"])))
+    mod.fuse()
+    with torch.no_grad():
+        y = yolo_ref._conv({k: v for k, v in mod.state_dict().items()}, "", torch.from_numpy(g["conv_x"]), 3, 2)
+    assert rel_err(y.numpy(), g["conv_y_fused"]) < 2e-6
+    gh = golden("yolov5n-0.5_forward")
+    m = Y.Model("yolov5n-0.5")
+    m.load_state_dict(synth_state_dict(m.state_dict(), int(gh["seed"])))
+    m.fuse()
+    with torch.no_grad():
+        z, heads = yolo_ref.forward(SPECS["yolov5n-0.5"], m.state_dict(), torch.from_numpy(gh["x"]))
+    for i, h in enumerate(heads):
+        np.testing.assert_allclose(h.numpy(), gh[f"head{i}"], rtol=0, atol=2e-5)
+    assert np.abs(z.numpy() - gh["z"]).max() <= 1e-5 * np.abs(gh["z"]).max()
+
+
+def test_get_bboxes_confs_areas_vs_reference_golden():
+    """onnx_utils.get_bboxes_confs_areas run by the reference itself on fp32 rows that straddle both thresholds:
+    the oracle restatement and this package's host helper must reproduce boxes, confs and percent areas exactly."""
+    from face_detection_and_recognition_amd.modules.yolov5_face.general import get_bboxes_confs_areas
+    from oracle import yolo_ref
+    g = golden("yolo_bboxes_confs_areas")
+    for fn in (yolo_ref.get_bboxes_confs_areas, get_bboxes_confs_areas):
+        boxes, confs, areas = fn(g["dets"].copy(), 0.7, 0.12, (1024, 576), (640, 640))
+        np.testing.assert_array_equal(boxes, g["boxes"])
+        np.testing.assert_array_equal(confs, g["confs"])
+        np.testing.assert_array_equal(areas, g["areas"])
+        assert areas.dtype == g["areas"].dtype and boxes.dtype == g["boxes"].dtype

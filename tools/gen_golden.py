@@ -200,6 +200,58 @@ def gen_yolo():
     save("yolo_box_iou", boxes=b1, iou=iou.numpy())
 
 
+def gen_yolo_blocks():
+    """Per-block fixtures of the YOLOv5-face path: Conv (+ fuse_conv_and_bn), StemBlock, ShuffleV2Block
+    s1 / s2, C3 (with and without shortcut), SPP at small maps -- the reference's own module classes on seeded weights --
+    plus the yolov5n-0.5 whole net (y5/models/yolov5n-0.5.yaml) and get_bboxes_confs_areas (onnx_utils.py:313-340)."""
+    ys = rh.import_reference_yolo()
+    C = ys.common
+    rng = np.random.default_rng(81)
+    out = {}
+
+    def run(tag, mod, shape, seed):
+        ys.torch_utils.initialize_weights(mod)    # as Model.__init__ does (yolo.py:152): BatchNorm eps = 1e-3
+        mod = mod.eval()
+        mod.load_state_dict(synth_state_dict(mod.state_dict(), seed=seed))
+        x = torch.from_numpy(rng.uniform(-1, 1, shape).astype(np.float32))
+        with torch.no_grad():
+            y = mod(x)
+        out[f"{tag}_seed"], out[f"{tag}_x"], out[f"{tag}_y"] = seed, x.numpy(), y.numpy()
+        return mod, x
+
+    conv, x = run("conv", C.Conv(16, 32, 3, 2), (2, 16, 32, 32), 601)
+    conv.conv = ys.torch_utils.fuse_conv_and_bn(conv.conv, conv.bn)          # what Model.fuse does (yolo.py:225-233)
+    with torch.no_grad():
+        out["conv_y_fused"] = conv.fuseforward(x).numpy()
+    run("conv1x1", C.Conv(24, 40, 1, 1), (2, 24, 20, 20), 602)
+    run("stem", C.StemBlock(3, 32, 3, 2), (2, 3, 64, 64), 603)
+    run("shuffle_s2", C.ShuffleV2Block(32, 128, 2), (2, 32, 16, 16), 604)
+    run("shuffle_s1", C.ShuffleV2Block(128, 128, 1), (2, 128, 8, 8), 605)
+    run("c3", C.C3(64, 64, 2), (2, 64, 16, 16), 606)
+    run("c3_noshortcut", C.C3(96, 64, 1, False), (2, 96, 8, 8), 607)
+    run("spp", C.SPP(128, 128, (3, 5, 7)), (2, 128, 8, 8), 608)
+    save("yolo_blocks", **out)
+
+    m = ys.build_model("yolov5n-0.5.yaml")
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=411))
+    m = m.fuse().eval()
+    x = torch.from_numpy(rng.uniform(0, 1, (1, 3, 128, 128)).astype(np.float32))
+    with torch.no_grad():
+        z, heads = m(x)
+    save("yolov5n-0.5_forward", seed=411, x=x.numpy(), z=z.numpy(), **{f"head{i}": h.numpy() for i, h in enumerate(heads)})
+
+    # get_bboxes_confs_areas on fp32 YOLO rows in 640^2 input pixels, frame 1024x576; rows straddle both thresholds
+    n = 48
+    xy0 = rng.uniform(0, 560, (n, 2))
+    wh = rng.uniform(2, 260, (n, 2))
+    wh[:8] = rng.uniform(18, 26, (8, 2))          # areas around 0.12 % of 640*640 (= 491.5 px^2)
+    dets = np.concatenate([xy0, xy0 + wh, rng.uniform(0.3, 1.0, (n, 1)), rng.uniform(0, 640, (n, 10)),
+                           np.ones((n, 1))], axis=1).astype(np.float32)
+    dets[8:12, 4] = np.float32(0.7) + np.array([-1e-6, 0, 1e-6, 2e-6], np.float32)
+    boxes, confs, areas = ys.onnx_utils.get_bboxes_confs_areas(dets.copy(), 0.7, 0.12, (1024, 576), (640, 640))
+    save("yolo_bboxes_confs_areas", dets=dets, boxes=boxes, confs=confs, areas=areas)
+
+
 def gen_tracker():
     """Face-tracker matching: the reference's own Net.check_if_face_exists / Net.add_face
     (fde/face_extraction/extract_and_label_faces_from_dataset.py:101-121) on seeded feature / box sequences.  The module
@@ -287,3 +339,5 @@ if __name__ == "__main__":
         gen_yolo()
     if "tracker" in which:
         gen_tracker()
+    if "yolo_blocks" in which:      # added in round 2; not part of the default list so the round-1 files stay untouched
+        gen_yolo_blocks()
