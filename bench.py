@@ -372,7 +372,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["pipeline", "c5"], default="pipeline")
-    ap.add_argument("--cpu-frames", type=int, default=96, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--box-px", type=float, default=W.BOX_PX,
                     help="synthetic detector's box size (model-input pixels); sets how candidates cluster in the NMS")

@@ -14,6 +14,7 @@ FP_OK = 0
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_YSTEM_U8 = 10
 # fp_act
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
 # fp_res_mode
@@ -38,6 +39,11 @@ class FpOp(C.Structure):
     ]
 
 
+class FpExt(C.Structure):
+    """Mirror of struct fp_ext: an external device buffer of a plan (pointer, readable bytes)."""
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
 class FpResizeItem(C.Structure):
     """Mirror of struct fp_resize_item."""
     _fields_ = [("src_image", C.c_int32), ("sx", C.c_int32), ("sy", C.c_int32), ("sw", C.c_int32), ("sh", C.c_int32),
@@ -56,13 +62,17 @@ SIGNATURES = {
     "fp_strerror": (C.c_char_p, [_I]),
     "fp_last_hip_error": (C.c_char_p, []),
     "fp_plan_run": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P]),
+    "fp_plan_run_ext": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, C.POINTER(FpExt), _I, _P]),
     "fp_plan_validate": (_I, [C.POINTER(FpOp), _I, _SZ, _SZ]),
     "fp_timer_create": (_I, [_I, C.POINTER(_P)]),
     "fp_timer_destroy": (None, [_P]),
     "fp_plan_run_timed": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P, _P, C.POINTER(C.c_ubyte)]),
+    "fp_plan_run_timed_ext": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, C.POINTER(FpExt), _I, _P, _P,
+                                   C.POINTER(C.c_ubyte)]),
     "fp_timer_accumulate": (_I, [_P, C.POINTER(_F), _I]),
     "fp_op_kernel_name": (C.c_char_p, [C.POINTER(FpOp)]),
     "fp_resize_normalize": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "fp_letterbox_tables": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "fp_dets_to_crops": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _I,
                                 _P, _P, _P, _P]),
     "fp_blaze_decode": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P]),

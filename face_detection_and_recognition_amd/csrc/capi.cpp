@@ -40,12 +40,14 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const bool spatial = op.kind != FP_OP_L2NORM && op.kind != FP_OP_COPY;
   const int OH = spatial ? op.OH : op.H, OW = spatial ? op.OW : op.W;
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
+  const bool ext_in = op.kind == FP_OP_YSTEM_U8;      // input lives in an external buffer (checked at launch)
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
-                    op.kind == FP_OP_YSTEM) ? op.Cout : op.Cin;
+                    op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // input extent
   const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
-  if (!span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
+  if (!ext_in && !span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
+  if (ext_in && op.in_off < 0) return FP_ERR_INVALID_ARG;
   const int64_t out_ch = (op.kind == FP_OP_CONV && op.res_mode == FP_RES_SHUFFLE2) ? 2 * (int64_t)Cout : Cout;
   const int64_t out_ext =
       (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (out_ch - 1) * op.out_cmul + 1;
@@ -53,7 +55,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
-      op.kind == FP_OP_DWPW || op.kind == FP_OP_YSTEM) {
+      op.kind == FP_OP_DWPW || op.kind == FP_OP_YSTEM || ext_in) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -88,14 +90,14 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.bias_off >= 0 && !span_ok(op.bias_off, (op.Cout + 3) / 4 * 4, weight_floats)) return FP_ERR_BOUNDS;
     if (op.bias_off >= 0 && op.res_mode != FP_RES_NONE) return FP_ERR_UNSUPPORTED;
   }
-  if (op.kind == FP_OP_YSTEM) {
-    if (op.Cin != 4 || op.res_C <= 0 || op.res_C > 32 || op.Cout > 32) return FP_ERR_UNSUPPORTED;
+  if (op.kind == FP_OP_YSTEM || op.kind == FP_OP_YSTEM_U8) {
+    if (op.Cin != (ext_in ? 3 : 4) || op.res_C <= 0 || op.res_C > 32 || op.Cout > 32) return FP_ERR_UNSUPPORTED;
     if (op.res_H <= 0 || op.res_W <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
     const int nb2 = fp_ystem_nb2(op);
     if (!span_ok(op.w_off, 40 * 32, weight_floats) || !span_ok(op.bias_off, 32, weight_floats)) return FP_ERR_BOUNDS;
     if (op.scale_off >= 0 && !span_ok(op.scale_off, 32, weight_floats)) return FP_ERR_BOUNDS;
     if (!span_ok(op.slope_off, (int64_t)nb2 * 16 * (32 + 2), weight_floats)) return FP_ERR_BOUNDS;
-    const int64_t res_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)op.res_H * op.res_W - 1) * op.res_ld + op.res_C;
+    const int64_t res_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)(op.OH / 2) * (op.OW / 2) - 1) * op.res_ld + op.res_C;
     if (!span_ok(op.res_off, res_ext, arena_floats)) return FP_ERR_BOUNDS;
   }
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV) {
@@ -129,6 +131,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_BLAZEBLOCK:
     case FP_OP_DWPW:
     case FP_OP_YSTEM:
+    case FP_OP_YSTEM_U8:
       return FP_OK;
     default:
       return FP_ERR_UNSUPPORTED;
@@ -177,7 +180,8 @@ const char* fp_op_kernel_name(const fp_op* op) {
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;
     case FP_OP_YSTEM:
-      snprintf(buf, sizeof(buf), "ystem_kernel<%d>", fp_ystem_nb2(*op));
+    case FP_OP_YSTEM_U8:
+      snprintf(buf, sizeof(buf), "ystem_kernel<%d, %s>", fp_ystem_nb2(*op), op->kind == FP_OP_YSTEM_U8 ? "true" : "false");
       return buf;
     default: return "?";
   }
@@ -192,7 +196,7 @@ int fp_plan_validate(const fp_op* ops, int n_ops, size_t weight_floats, size_t a
   return FP_OK;
 }
 
-static int launch_op(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+static int launch_op(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s) {
   switch (op.kind) {
     case FP_OP_CONV: return fp_launch_conv(op, weights, arena, s);
     case FP_OP_DWCONV: return fp_launch_dwconv(op, weights, arena, s);
@@ -203,24 +207,29 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, hipStr
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
     case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
+    case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);
     default: return FP_ERR_UNSUPPORTED;
   }
 }
 
-int fp_plan_run(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
-                size_t arena_floats, void* stream) {
-  if (!weights || !arena) return FP_ERR_INVALID_ARG;
+int fp_plan_run_ext(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
+                    size_t arena_floats, const fp_ext* ext, int n_ext, void* stream) {
+  if (!weights || !arena || n_ext < 0 || (n_ext > 0 && !ext)) return FP_ERR_INVALID_ARG;
   int rc = fp_plan_validate(ops, n_ops, weight_floats, arena_floats);
   if (rc != FP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   for (int i = 0; i < n_ops; ++i) {
-    rc = launch_op(ops[i], weights, arena, s);
+    rc = launch_op(ops[i], weights, arena, ext, n_ext, s);
     if (rc != FP_OK) return rc;
   }
   return FP_OK;
 }
 
-// ---- per-op timing with HIP events recorded on the launch stream (bench.py's live roofline figures) ----
+int fp_plan_run(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
+                size_t arena_floats, void* stream) {
+  return fp_plan_run_ext(ops, n_ops, weights, weight_floats, arena, arena_floats, nullptr, 0, stream);
+}
+
 struct fp_timer {
   int n;
   hipEvent_t* start;
@@ -259,25 +268,29 @@ void fp_timer_destroy(void* timer) {
   delete t;
 }
 
-int fp_plan_run_timed(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
-                      size_t arena_floats, void* stream, void* timer, const unsigned char* op_mask) {
+int fp_plan_run_timed_ext(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
+                          size_t arena_floats, const fp_ext* ext, int n_ext, void* stream, void* timer,
+                          const unsigned char* op_mask) {
   fp_timer* t = (fp_timer*)timer;
-  if (!weights || !arena || !t || !op_mask || t->n < n_ops) return FP_ERR_INVALID_ARG;
+  if (!weights || !arena || !t || !op_mask || t->n < n_ops || n_ext < 0 || (n_ext > 0 && !ext)) return FP_ERR_INVALID_ARG;
   int rc = fp_plan_validate(ops, n_ops, weight_floats, arena_floats);
   if (rc != FP_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   for (int i = 0; i < n_ops; ++i) {
     t->used[i] = op_mask[i];
     if (op_mask[i]) (void)hipEventRecord(t->start[i], s);
-    rc = launch_op(ops[i], weights, arena, s);
+    rc = launch_op(ops[i], weights, arena, ext, n_ext, s);
     if (rc != FP_OK) return rc;
     if (op_mask[i]) (void)hipEventRecord(t->stop[i], s);
   }
   return FP_OK;
 }
 
-// Adds the elapsed ms of every op timed by the LAST fp_plan_run_timed call into ms_accum[i]
-// (waits for those events; call it outside any latency-critical section).
+int fp_plan_run_timed(const fp_op* ops, int n_ops, const float* weights, size_t weight_floats, float* arena,
+                      size_t arena_floats, void* stream, void* timer, const unsigned char* op_mask) {
+  return fp_plan_run_timed_ext(ops, n_ops, weights, weight_floats, arena, arena_floats, nullptr, 0, stream, timer, op_mask);
+}
+
 int fp_timer_accumulate(void* timer, float* ms_accum, int n_ops) {
   fp_timer* t = (fp_timer*)timer;
   if (!t || !ms_accum || n_ops > t->n) return FP_ERR_INVALID_ARG;

@@ -15,6 +15,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FP_WAVE 64
 
+// SiLU x * sigmoid(x) (nn.SiLU, y5/models/common.py:47) with the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: <= 1 ulp
+// each, relative error of the result ~1e-6 x |x|/16): 5 VALU instructions.  The IEEE expf + division form costs 26 and,
+// applied to every conv output of YOLOv5-face, was ~3 ms of VALU issue per 256-image forward pass.  x -> -inf gives
+// exp2 = +inf, rcp = 0, result -0; x -> +inf gives x.  Decisions that must be bit-exact (decode / NMS, post.hip)
+// do not use this.
+__device__ __forceinline__ float fp_silu(float x) {
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // Per-thread record of the last HIP error text (fp_last_hip_error()).
 void fp_set_hip_error(hipError_t e);
 
@@ -46,4 +56,5 @@ bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-p
 int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 int fp_ystem_nb2(const fp_op& op);
+int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s);
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd);  // conv_igemm template arguments for an op

@@ -45,7 +45,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
     case FP_ACT_RELU: return v > 0.f ? v : 0.f;
     case FP_ACT_PRELU: return v > 0.f ? v : v * slope;
-    case FP_ACT_SILU: return v / (1.0f + expf(-v));
+    case FP_ACT_SILU: return fp_silu(v);
     default: return v;
   }
 }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, PWD ? (NB == 4 ? 3 : 4) : 1) void conv_igemm_k
             const float pre = (RES && !after && !shuf) ? rr[j][e] : 0.f;
             const float x = RES ? v[e] + pre : v[e];
             float y;
-            if (SILU) y = x / (1.0f + expf(-x));
+            if (SILU) y = fp_silu(x);
             else y = x > 0.f ? x : __builtin_fmaf(x, sl[j][e], 0.0f);
             o[e] = (RES && after) ? y + rr[j][e] : y;
           }

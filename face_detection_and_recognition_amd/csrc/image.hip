@@ -10,6 +10,7 @@
 // against oracle/image_ref.py, which restates the same arithmetic in numpy.
 // One thread per canvas pixel; HBM-bound (reads each source byte once, writes 16 B per pixel).
 #include "common.h"
+#include "letterbox.h"
 
 namespace {
 
@@ -20,24 +21,6 @@ struct ResizeArgs {
   const float* lut;
   int n_frames, fh, fw, n_items, ch, cw, cc, pad_value, swap_rb;
 };
-
-__device__ __forceinline__ void coef(int d, double scale, int ssize, int& s0, int& s1, int& a0, int& a1) {
-  float f = (float)(((double)d + 0.5) * scale - 0.5);
-  int s = (int)floorf(f);
-  f -= (float)s;
-  if (s < 0) {
-    f = 0.f;
-    s = 0;
-  }
-  if (s >= ssize - 1) {
-    f = 0.f;
-    s = ssize - 1;
-  }
-  s0 = s;
-  s1 = min(s + 1, ssize - 1);
-  a0 = (int)rintf((1.f - f) * 2048.f);
-  a1 = (int)rintf(f * 2048.f);
-}
 
 __global__ __launch_bounds__(256) void resize_normalize_kernel(ResizeArgs p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -58,8 +41,8 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(ResizeArgs p) {
                       y < it.dy + it.dh && it.src_image >= 0 && it.src_image < p.n_frames;
   if (inside) {
     int sx0, sx1, ax0, ax1, sy0, sy1, by0, by1;
-    coef(x - it.dx, (double)it.sw / (double)it.dw, it.sw, sx0, sx1, ax0, ax1);
-    coef(y - it.dy, (double)it.sh / (double)it.dh, it.sh, sy0, sy1, by0, by1);
+    fp_lb_coef(x - it.dx, (double)it.sw / (double)it.dw, it.sw, sx0, sx1, ax0, ax1);
+    fp_lb_coef(y - it.dy, (double)it.sh / (double)it.dh, it.sh, sy0, sy1, by0, by1);
     const uint8_t* f = p.frames + (long)it.src_image * p.fh * p.fw * 3;
     const uint8_t* r0 = f + ((long)(it.sy + sy0) * p.fw + it.sx) * 3;
     const uint8_t* r1 = f + ((long)(it.sy + sy1) * p.fw + it.sx) * 3;
@@ -67,8 +50,7 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(ResizeArgs p) {
     for (int c = 0; c < 3; ++c) {
       const int h0 = (int)r0[sx0 * 3 + c] * ax0 + (int)r0[sx1 * 3 + c] * ax1;
       const int h1 = (int)r1[sx0 * 3 + c] * ax0 + (int)r1[sx1 * 3 + c] * ax1;
-      int o = (((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      v[c] = min(max(o, 0), 255);
+      v[c] = fp_lb_vpass(h0, h1, by0, by1);
     }
   } else {
     v[0] = v[1] = v[2] = p.pad_value;
@@ -102,6 +84,62 @@ extern "C" int fp_resize_normalize(const uint8_t* frames, int n_frames, int fram
                pad_value, swap_rb};
   const long total = (long)n_items * canvas_h * canvas_w;
   hipLaunchKernelGGL(resize_normalize_kernel, dim3((unsigned)fp_ceil_div(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tap tables of ONE resize geometry (letterbox.h) for the stems that read u8 frames directly.
+namespace {
+
+struct LbTableArgs {
+  fp_lb_tap* xtab;
+  fp_lb_tap* ytab;
+  int fw, cw, ch, sx, sy, sw, sh, dx, dy, dw, dh, pad_value, swap_rb;
+};
+
+__global__ __launch_bounds__(256) void letterbox_tables_kernel(LbTableArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < p.cw) {
+    fp_lb_tap t = {0, 0};
+    if (p.dw > 0 && i >= p.dx && i < p.dx + p.dw) {
+      int s0, s1, a0, a1;
+      fp_lb_coef(i - p.dx, (double)p.sw / (double)p.dw, p.sw, s0, s1, a0, a1);
+      const int off0 = (p.sx + s0) * 3, off1 = (p.sx + s1) * 3;
+      const int base = min(off0, p.fw * 3 - 8);        // the 8-byte window never leaves the frame row
+      t.a = base;
+      t.b = (off0 - base) | ((off1 - base) << 3) | (a0 << 6) | (a1 << 18) | FP_LB_VALID;
+    }
+    p.xtab[i] = t;
+  } else if (i < p.cw + p.ch) {
+    const int y = i - p.cw;
+    fp_lb_tap t = {0, 0};
+    if (p.dh > 0 && y >= p.dy && y < p.dy + p.dh) {
+      int s0, s1, b0, b1;
+      fp_lb_coef(y - p.dy, (double)p.sh / (double)p.dh, p.sh, s0, s1, b0, b1);
+      t.a = (p.sy + s0) | ((p.sy + s1) << 16);
+      t.b = b0 | (b1 << 12) | FP_LB_VALID;
+    }
+    p.ytab[y] = t;
+  } else if (i == p.cw + p.ch) {
+    const fp_lb_tap t = {p.pad_value, p.swap_rb};     // trailer: pad colour (u8 value), swap R/B
+    p.xtab[i] = t;
+  }
+}
+
+}  // namespace
+
+extern "C" int fp_letterbox_tables(int frame_h, int frame_w, int canvas_h, int canvas_w, int sx, int sy, int sw, int sh,
+                                   int dx, int dy, int dw, int dh, int pad_value, int swap_rb, int32_t* tables,
+                                   void* stream) {
+  if (!tables || frame_h <= 0 || frame_h > 65535 || frame_w < 3 || canvas_h <= 0 || canvas_w <= 0) return FP_ERR_INVALID_ARG;
+  if (sx < 0 || sy < 0 || sw <= 0 || sh <= 0 || sx + sw > frame_w || sy + sh > frame_h) return FP_ERR_INVALID_ARG;
+  if (dw < 0 || dh < 0 || dx < 0 || dy < 0 || dx + dw > canvas_w || dy + dh > canvas_h) return FP_ERR_INVALID_ARG;
+  if (pad_value < 0 || pad_value > 255) return FP_ERR_INVALID_ARG;
+  LbTableArgs a{(fp_lb_tap*)tables, (fp_lb_tap*)tables + canvas_w, frame_w, canvas_w, canvas_h, sx, sy, sw, sh, dx, dy, dw, dh,
+                pad_value, swap_rb != 0};
+  hipLaunchKernelGGL(letterbox_tables_kernel, dim3((unsigned)fp_ceil_div(canvas_w + canvas_h + 1, 256)), dim3(256), 0,
                      (hipStream_t)stream, a);
   FP_CHECK_LAUNCH();
   return FP_OK;

@@ -19,6 +19,7 @@
 // stem_2b and stem_3 stay FP_OP_CONVs.  Same products in the same k order as conv.hip for stem_1 (k = tap*4 + c);
 // stem_2a sums k in the order 16j + 4g + e of its fragment layout (fp32 reassociation only).
 #include "common.h"
+#include "letterbox.h"
 
 namespace {
 
@@ -40,11 +41,15 @@ struct YStemArgs {
   const float* bi2;     // [NB2*16]
   int H, W, H1, W1, W2o, C1, C2, a_ld, p_ld, tiles_x, tiles_per_img, ntiles;
   long in_ns, a_ns, p_ns;
+  // U8 input (the letterbox fused into the staging, letterbox.h): frames [N][fh][fw][3] u8, tap tables of the H x W canvas
+  const uint8_t* frames;
+  const fp_lb_tap* xtab;
+  const fp_lb_tap* ytab;
+  const float* lut;
+  long frame_bytes, row_bytes;
 };
 
-__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
-
-template <int NB2>
+template <int NB2, bool U8>
 __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
   constexpr int C2S = NB2 * 16;         // staged channels per `a` pixel
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -52,12 +57,23 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
   float* S1 = Img + (IR * IC * 4 > 256 * C2S ? IR * IC * 4 : 256 * C2S);   // [256][S1LD]
   float* W1s = S1 + 256 * S1LD;                   // [K1PAD/4][32][4]
   float* W2s = W1s + K1PAD * 32;                  // [2][4][C2S][4]
+  float* LutS = W2s + 32 * C2S;                   // [256] normalisation LUT (U8 input only)
+  fp_lb_tap* TabS = (fp_lb_tap*)(LutS + 256);     // [W + H + 1] tap tables (U8 input only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
   for (int i = tid; i < K1PAD * 32 / 4; i += 256) *(f32x4*)&W1s[i * 4] = *(const f32x4*)(p.w1 + (long)i * 4);
   for (int i = tid; i < 8 * C2S; i += 256) *(f32x4*)&W2s[i * 4] = *(const f32x4*)(p.w2 + (long)i * 4);
+  int pad_value = 0, swap_rb = 0;
+  if (U8) {
+    LutS[tid] = p.lut[tid];
+    for (int i = tid; i < p.W + p.H; i += 256) TabS[i] = p.xtab[i];
+    const fp_lb_tap tr = p.xtab[p.W + p.H];    // trailer entry of the tables: { pad colour, swap R/B }
+    pad_value = tr.a;
+    swap_rb = tr.b;
+    __syncthreads();
+  }
   const float sc1 = p.sc1 ? p.sc1[lr] : 1.f, bi1 = p.bi1[lr];
   float sc2[NB2], bi2[NB2];
 #pragma unroll
@@ -73,31 +89,49 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
     pos = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
   }
 
+  // staging of a tile's input pixels: issue (registers) and write (LDS) are split so that the NEXT tile's loads are
+  // in flight during phase 2 and the stores of the current tile
+  constexpr int NSLOT = (IR * IC + 255) / 256;
+  f32x4 stg[U8 ? 1 : NSLOT];
+  fp_lb_raw raw[U8 ? NSLOT : 1];
+  fp_lb_tap xt[U8 ? NSLOT : 1], yt[U8 ? NSLOT : 1];
+  unsigned stg_ok = 0;
+  auto issue_stage = [&](int tile) {
+    const int img = tile / p.tiles_per_img, tin = tile - img * p.tiles_per_img;
+    const int ty = tin / p.tiles_x, tx = tin - ty * p.tiles_x;
+    const int iy0 = 2 * ty * TR - 1, ix0 = 2 * tx * TC - 1;
+    stg_ok = 0;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int i = tid + 256 * j;
+      const int r = i / IC, c = i - r * IC;
+      const int iy = iy0 + r, ix = ix0 + c;
+      if (i < IR * IC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) stg_ok |= 1u << j;
+      const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+      if (U8) {   // the canvas pixel is resampled from the u8 frame: its two 8-byte tap windows are what is staged
+        xt[j] = TabS[cx];
+        yt[j] = TabS[p.W + cy];
+        raw[j] = fp_lb_issue(p.frames + (long)img * p.frame_bytes, p.row_bytes, xt[j], yt[j]);
+      } else {
+        stg[j] = *(const f32x4*)(p.in + (long)img * p.in_ns + ((long)cy * p.W + cx) * 4);
+      }
+    }
+  };
+
+  if (pos < p.ntiles) issue_stage(pos);
   for (int tile = pos; tile < p.ntiles; tile += G) {
     const int img = tile / p.tiles_per_img, tin = tile - img * p.tiles_per_img;
     const int ty = tin / p.tiles_x, tx = tin - ty * p.tiles_x;
     const int y1_0 = ty * TR, x1_0 = tx * TC;       // s1 coordinates of the tile's first pixel
-    const int iy0 = 2 * y1_0 - 1, ix0 = 2 * x1_0 - 1;
-    const float* ib = p.in + (long)img * p.in_ns;
 
-    // ---- phase 0: input pixels -> LDS (all loads issued, then the writes; zero padding applied at the write) ----
-    {
-      constexpr int NSLOT = (IR * IC + 255) / 256;
-      f32x4 v[NSLOT];
-      bool ok[NSLOT];
+    // ---- phase 0: staged input pixels -> LDS (zero padding applied at the write) ----
 #pragma unroll
-      for (int j = 0; j < NSLOT; ++j) {
-        const int i = tid + 256 * j;
-        const int r = i / IC, c = i - r * IC;
-        const int iy = iy0 + r, ix = ix0 + c;
-        ok[j] = i < IR * IC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        v[j] = *(const f32x4*)(ib + ((long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)) * 4);
-      }
-#pragma unroll
-      for (int j = 0; j < NSLOT; ++j) {
-        const int i = tid + 256 * j;
-        if (i < IR * IC) *(f32x4*)&Img[i * 4] = ok[j] ? v[j] : z4;
-      }
+    for (int j = 0; j < NSLOT; ++j) {
+      const int i = tid + 256 * j;
+      f32x4 v;
+      if (U8) v = fp_lb_finish(raw[j], xt[j], yt[j], LutS, pad_value, swap_rb);
+      else v = stg[j];
+      if (i < IR * IC) *(f32x4*)&Img[i * 4] = ((stg_ok >> j) & 1u) ? v : z4;
     }
     __syncthreads();
 
@@ -129,11 +163,12 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int x = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        s0[x * S1LD] = silu(acc0[reg] * sc1 + bi1);
-        s0[(TC + x) * S1LD] = silu(acc1[reg] * sc1 + bi1);
+        s0[x * S1LD] = fp_silu(acc0[reg] * sc1 + bi1);
+        s0[(TC + x) * S1LD] = fp_silu(acc1[reg] * sc1 + bi1);
       }
     }
     __syncthreads();   // S1 complete; Img is free
+    if (tile + G < p.ntiles) issue_stage(tile + G);
 
     // ---- phase 2: stem_2a (1x1, 16x16x4 MFMA) on S1 -> staging;  wave w owns pixels 64w .. 64w + 63 ----
     {
@@ -166,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
         for (int nb = 0; nb < NB2; ++nb)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            At[(wave * 64 + mt * 16 + 4 * g + reg) * C2S + nb * 16 + r16] = silu(acc[mt][nb][reg] * sc2[nb] + bi2[nb]);
+            At[(wave * 64 + mt * 16 + 4 * g + reg) * C2S + nb * 16 + r16] = fp_silu(acc[mt][nb][reg] * sc2[nb] + bi2[nb]);
     }
     // ---- max pool 2x2 of S1 -> concat half (needs only S1: issued before the barrier that publishes `a`) ----
     {
@@ -203,9 +238,10 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
   }
 }
 
-size_t ystem_lds_bytes(int nb2) {
+size_t ystem_lds_bytes(int nb2, int table_entries) {
   const size_t img = (size_t)IR * IC * 4, st = (size_t)256 * nb2 * 16;
-  return 4 * ((img > st ? img : st) + (size_t)256 * S1LD + (size_t)K1PAD * 32 + (size_t)8 * nb2 * 16 * 4);
+  return 4 * ((img > st ? img : st) + (size_t)256 * S1LD + (size_t)K1PAD * 32 + (size_t)8 * nb2 * 16 * 4 + 256) +
+         8 * (size_t)table_entries;
 }
 
 }  // namespace
@@ -215,18 +251,15 @@ size_t ystem_lds_bytes(int nb2) {
 // pooled size); w_off/scale_off/bias_off = stem_1 (packed as FP_OP_CONV, [32] scale / bias); slope_off = stem_2a blob.
 int fp_ystem_nb2(const fp_op& op) { return (op.Cout + 15) / 16; }
 
-int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
-  if (op.Cin != 4 || op.in_ld != 4 || op.KH != 3 || op.KW != 3 || op.stride != 2 || op.pad_t != 1 || op.pad_l != 1)
-    return FP_ERR_UNSUPPORTED;
-  if (op.H % 4 || op.W % 4 || op.OH != op.H / 2 || op.OW != op.W / 2 || op.res_H != op.OH / 2 || op.res_W != op.OW / 2)
-    return FP_ERR_UNSUPPORTED;
+static int ystem_fill(const fp_op& op, const float* weights, float* arena, YStemArgs& a) {
+  if (op.KH != 3 || op.KW != 3 || op.stride != 2 || op.pad_t != 1 || op.pad_l != 1) return FP_ERR_UNSUPPORTED;
+  if (op.H % 4 || op.W % 4 || op.OH != op.H / 2 || op.OW != op.W / 2) return FP_ERR_UNSUPPORTED;
   if (op.res_C <= 0 || op.res_C > 32 || op.res_C % 4 || op.Cout <= 0 || op.Cout > 32 || op.Cout % 4) return FP_ERR_UNSUPPORTED;
-  if (op.in_off % 4 || op.out_off % 4 || op.res_off % 4 || op.out_ld % 4 || op.res_ld % 4 || op.in_ns % 4 ||
-      op.out_ns % 4 || op.res_ns % 4 || op.out_cmul != 1)
+  if (op.out_off % 4 || op.res_off % 4 || op.out_ld % 4 || op.res_ld % 4 || op.out_ns % 4 || op.res_ns % 4 || op.out_cmul != 1)
     return FP_ERR_ALIGNMENT;
   const int nb2 = fp_ystem_nb2(op);
-  YStemArgs a;
-  a.in = arena + op.in_off;
+  a.in = nullptr;
+  a.frames = nullptr;
   a.a_out = arena + op.out_off;
   a.p_out = arena + op.res_off;
   a.w1 = weights + op.w_off;
@@ -236,22 +269,31 @@ int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStre
   a.w2 = blob;
   a.sc2 = blob + 8 * nb2 * 16 * 4;          // [nb2*16] scale then [nb2*16] bias (scale = 1 when the BN is folded)
   a.bi2 = a.sc2 + nb2 * 16;
-  a.H = op.H; a.W = op.W; a.H1 = op.OH; a.W1 = op.OW; a.W2o = op.res_W;
+  a.H = op.H; a.W = op.W; a.H1 = op.OH; a.W1 = op.OW; a.W2o = op.OW / 2;
   a.C1 = op.res_C; a.C2 = op.Cout; a.a_ld = op.out_ld; a.p_ld = op.res_ld;
   a.in_ns = op.in_ns; a.a_ns = op.out_ns; a.p_ns = op.res_ns;
   a.tiles_x = fp_ceil_div(op.OW, TC);
   a.tiles_per_img = a.tiles_x * fp_ceil_div(op.OH, TR);
   a.ntiles = op.N * a.tiles_per_img;
-  const size_t lds = ystem_lds_bytes(nb2);
-  int grid = 512;                             // two workgroups per CU (LDS ~62 KiB each), persistent
+  a.xtab = a.ytab = nullptr;
+  a.lut = nullptr;
+  a.frame_bytes = a.row_bytes = 0;
+  return FP_OK;
+}
+
+template <bool U8>
+static int ystem_launch(const fp_op& op, const YStemArgs& a, hipStream_t s) {
+  const int nb2 = fp_ystem_nb2(op);
+  const size_t lds = ystem_lds_bytes(nb2, U8 ? op.H + op.W : 0);
+  int grid = 512;                             // two workgroups per CU (LDS ~63 KiB each), persistent
   if (grid > a.ntiles) grid = a.ntiles;
   hipError_t ae;
   if (nb2 == 1) {
-    ae = hipFuncSetAttribute((const void*)ystem_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (ae == hipSuccess) hipLaunchKernelGGL((ystem_kernel<1>), dim3(grid), dim3(256), lds, s, a);
+    ae = hipFuncSetAttribute((const void*)ystem_kernel<1, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ae == hipSuccess) hipLaunchKernelGGL((ystem_kernel<1, U8>), dim3(grid), dim3(256), lds, s, a);
   } else {
-    ae = hipFuncSetAttribute((const void*)ystem_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (ae == hipSuccess) hipLaunchKernelGGL((ystem_kernel<2>), dim3(grid), dim3(256), lds, s, a);
+    ae = hipFuncSetAttribute((const void*)ystem_kernel<2, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ae == hipSuccess) hipLaunchKernelGGL((ystem_kernel<2, U8>), dim3(grid), dim3(256), lds, s, a);
   }
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
@@ -259,4 +301,35 @@ int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStre
   }
   FP_CHECK_LAUNCH();
   return FP_OK;
+}
+
+int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  if (op.Cin != 4 || op.in_ld != 4 || op.in_off % 4 || op.in_ns % 4) return FP_ERR_UNSUPPORTED;
+  if (op.res_H != op.OH / 2 || op.res_W != op.OW / 2) return FP_ERR_UNSUPPORTED;
+  YStemArgs a;
+  const int rc = ystem_fill(op, weights, arena, a);
+  if (rc != FP_OK) return rc;
+  a.in = arena + op.in_off;
+  return ystem_launch<false>(op, a, s);
+}
+
+// FP_OP_YSTEM_U8: the same op reading the u8 frames through the letterbox tap tables (include/facepath.h).
+int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s) {
+  const long e = op.in_off;
+  if (e < 0 || e + 2 >= n_ext || !ext) return FP_ERR_INVALID_ARG;
+  const int fh = op.res_H, fw = op.res_W;
+  if (op.Cin != 3 || fh <= 0 || fw < 3) return FP_ERR_INVALID_ARG;
+  if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 1) * 8 || op.H + op.W > 2048 ||
+      ext[e + 2].bytes < 256 * sizeof(float) || !ext[e].ptr || !ext[e + 1].ptr || !ext[e + 2].ptr)
+    return FP_ERR_BOUNDS;
+  YStemArgs a;
+  const int rc = ystem_fill(op, weights, arena, a);
+  if (rc != FP_OK) return rc;
+  a.frames = (const uint8_t*)ext[e].ptr;
+  a.xtab = (const fp_lb_tap*)ext[e + 1].ptr;
+  a.ytab = a.xtab + op.W;
+  a.lut = (const float*)ext[e + 2].ptr;
+  a.row_bytes = (long)fw * 3;
+  a.frame_bytes = (long)fh * fw * 3;
+  return ystem_launch<true>(op, a, s);
 }

@@ -49,6 +49,25 @@ def letterbox_batch(frames_u8, new_size, lut, canvas, pad_value=125, swap_rb=Fal
     return canvas
 
 
+def bind_letterbox(plan, frames_u8, lut, pad_value=125, swap_rb=False):
+    """Point a plan whose first op reads u8 frames (FP_OP_*_U8) at a batch: external buffers [frames, tap tables, LUT].
+    The tap tables of the plan's (frame size -> canvas size) letterbox are computed once per plan on the device
+    (fp_letterbox_tables: the same arithmetic as fp_resize_normalize, one entry per canvas column / row)."""
+    B, fh, fw, _ = frames_u8.shape
+    assert plan.frame_hw == (fh, fw) and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    ch, cw = plan.canvas_hw
+    key = (int(pad_value), bool(swap_rb))
+    if plan.tables is None or plan.tables[0] != key:
+        sw, sh, left, top = letterbox_geometry(fw, fh, cw, ch)
+        t = torch.empty(((cw + ch + 1) * 2,), dtype=torch.int32, device=frames_u8.device)
+        L.check(L.load().fp_letterbox_tables(fh, fw, ch, cw, 0, 0, fw, fh, left, top, sw, sh, int(pad_value),
+                                             int(bool(swap_rb)), L.ptr(t), L.current_stream(frames_u8.device)),
+                "fp_letterbox_tables")
+        plan.tables = (key, t)
+    plan.set_ext([frames_u8, plan.tables[1], lut])
+    return plan
+
+
 def pad_resize_image(cv2_img: np.ndarray, new_size: Tuple[int, int] = (640, 480),
                      color: Tuple[int, int, int] = (125, 125, 125), device="cuda") -> np.ndarray:
     """image.py:31-59 for one image (numpy in, numpy out) through the device kernel."""

@@ -135,19 +135,26 @@ class StemBlock(_NoCompute):
             return None, npy(conv.conv.bias)
         return _bn_sb(conv.bn)
 
-    def emit(self, pb, x, out=None):
+    def fusable(self, H, W):
+        """FP_OP_YSTEM handles the block's head (stem_1 -> LDS -> stem_2a + maxpool) for these shapes."""
+        c, s1c = self.c2, self.stem_1
+        return (StemBlock.FUSE and H % 4 == 0 and W % 4 == 0 and c <= 32 and c % 8 == 0 and s1c.k == 3 and s1c.s == 2 and
+                s1c.p == 1 and s1c.act and self.stem_2a.act)
+
+    def emit(self, pb, x, out=None, u8=None):
+        """u8 = (H, W, frame_h, frame_w, ext_index): the block reads the u8 frames itself (letterbox fused into the
+        staging, FP_OP_YSTEM_U8) and x is None."""
         c = self.c2
         s1c = self.stem_1
-        if (StemBlock.FUSE and x.C == 4 and x.buf.ld == 4 and x.coff == 0 and x.H % 4 == 0 and x.W % 4 == 0 and
-                c <= 32 and c % 8 == 0 and s1c.k == 3 and s1c.s == 2 and s1c.p == 1 and s1c.act and self.stem_2a.act):
+        if u8 is not None or (x.C == 4 and x.buf.ld == 4 and x.coff == 0 and self.fusable(x.H, x.W)):
             # stem_1 -> (LDS) -> stem_2a + maxpool in one kernel (FP_OP_YSTEM): stem_1's output never reaches HBM
-            H1, W1 = x.H // 2, x.W // 2
+            H1, W1 = (x.H // 2, x.W // 2) if u8 is None else (u8[0] // 2, u8[1] // 2)
             a = pb.new_buf(H1, W1, c // 2)
             cat = pb.new_buf(H1 // 2, W1 // 2, 2 * c)
             sc1, bi1 = self._sb(s1c)
             sc2, bi2 = self._sb(self.stem_2a)
             pb.ystem(x, npy(s1c.conv.weight), sc1, bi1, npy(self.stem_2a.conv.weight), sc2, bi2, a.view(0, cpad(c // 2)),
-                     cat.view(c, c))
+                     cat.view(c, c), u8=u8)
             self.stem_2b.emit(pb, a.view(0, c // 2), out=cat.view(0, c))
             pb.free(a)
             y = self.stem_3.emit(pb, cat.view(), out=out)
@@ -402,10 +409,18 @@ class Model(nn.Module):
     # ---- plan ----
     CONCAT_IN_PLACE = True   # class-wide switch: False copies every Concat input (A/B parity tests)
 
-    def _emit(self, N, H=640, W=640):
+    FUSE_LETTERBOX = True    # class-wide switch: False keeps the stand-alone letterbox kernel (A/B parity tests)
+
+    def letterbox_fusable(self, H, W):
+        first = self.model[0]
+        return Model.FUSE_LETTERBOX and isinstance(first, StemBlock) and first.fusable(H, W)
+
+    def _emit(self, N, H=640, W=640, frame_hw=None):
+        """frame_hw = (frame_h, frame_w): the plan reads u8 frames of that size directly (no fp32 canvas, no letterbox
+        kernel: external buffers 0..2 = frames, tap tables, LUT); None: the plan input is the NHWC fp32 canvas."""
         assert H % 32 == 0 and W % 32 == 0
         pb = PlanBuilder(N)
-        inp = pb.new_buf(H, W, 3)
+        inp = pb.new_buf(H, W, 3) if frame_hw is None else None
         det = self.model[-1]
         layers = list(self.model)
 
@@ -437,7 +452,8 @@ class Model(nn.Module):
         heads = []
         for m in layers:
             fs = [m.f] if isinstance(m.f, int) else m.f
-            ins = [inp.view() if (j == -1 and m.i == 0) else outs[m.i - 1 if j == -1 else j] for j in fs]
+            ins = [(inp.view() if inp is not None else None) if (j == -1 and m.i == 0) else outs[m.i - 1 if j == -1 else j]
+                   for j in fs]
             if isinstance(m, Detect):
                 for src, conv in zip(ins, m.m):
                     hb = pb.new_buf(src.H, src.W, det.no * det.na)
@@ -470,6 +486,8 @@ class Model(nn.Module):
                     if y is not xin:
                         pb.free(y.buf)
                     y = y2
+            elif m.i == 0 and frame_hw is not None:
+                y = m.emit(pb, None, out=target, u8=(H, W, frame_hw[0], frame_hw[1], 0))
             else:
                 y = m.emit(pb, xin, out=target) if target is not None else m.emit(pb, xin)
             outs[m.i] = y
@@ -501,19 +519,20 @@ class Model(nn.Module):
                 h, w = math.ceil(((h + 2 - 3) // 2 + 1) / 2), math.ceil(((w + 2 - 3) // 2 + 1) / 2)
         return h, w
 
-    def _build(self, N, H, W, cache=None):
-        pb, inp, heads, z_off, n_rows = self._emit(N, H, W)
+    def _build(self, N, H, W, cache=None, frame_hw=None):
+        pb, inp, heads, z_off, n_rows = self._emit(N, H, W, frame_hw)
         plan = CompiledPlan(pb, self._device(), cache)
-        plan.input = plan.buf_tensor(inp, N)
+        plan.input = plan.buf_tensor(inp, N) if inp is not None else None
+        plan.frame_hw, plan.canvas_hw, plan.tables = frame_hw, (H, W), None
         plan.heads = [plan.buf_tensor(hb, N) for hb in heads]
         plan.z = plan.arena[z_off: z_off + N * n_rows * 16].view(N, n_rows, 16)
         plan.n_rows = n_rows
         return plan
 
-    def plan_for(self, N, H=640, W=640):
+    def plan_for(self, N, H=640, W=640, frame_hw=None):
         if self._device().type != "cuda":
             raise L.FacepathError("YOLOv5-face runs only on a HIP device (model.to('cuda')); there is no CPU path")
-        return self._plans.get((N, H, W), lambda cache: self._build(N, H, W, cache))
+        return self._plans.get((N, H, W, frame_hw), lambda cache: self._build(N, H, W, cache, frame_hw))
 
     def run_plan(self, plan):
         """Forward + Detect decode on whatever is in plan.input.  Returns z (N, n_rows, 16): zero-copy, a view into

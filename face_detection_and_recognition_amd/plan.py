@@ -309,17 +309,29 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * G + opix * G + opix * G + opix * cout))
         return out
 
-    def ystem(self, x, w1, scale1, bias1, w2, scale2, bias2, a_out, pool_out):
+    def ystem(self, x, w1, scale1, bias1, w2, scale2, bias2, a_out, pool_out, u8=None):
         """Head of YOLOv5-face's StemBlock (common.py:58-73) as ONE op: stem_1 (3x3 s2 p1, SiLU) stays in LDS,
         stem_2a (1x1, SiLU) -> a_out, maxpool2x2(stem_1) -> pool_out (a channel slice of stem_3's concat buffer).
         scale1 / scale2 = None when the BatchNorm is folded into the conv (Model.fuse())."""
         c1, c2 = w1.shape[0], w2.shape[0]
-        assert x.C == 4 and x.buf.ld == 4 and x.coff == 0
         assert w1.shape[2:] == (3, 3) and w2.shape[1] == c1 and w2.shape[2:] == (1, 1)
         assert c1 <= 32 and a_out.C <= 32 and pool_out.C >= c1 and pool_out.cmul == 1 and a_out.cmul == 1
-        H1, W1 = x.H // 2, x.W // 2
-        assert x.H % 4 == 0 and x.W % 4 == 0 and (a_out.H, a_out.W) == (H1, W1) and (pool_out.H, pool_out.W) == (H1 // 2, W1 // 2)
-        op = self._base(L.OP_YSTEM, x, a_out, H1, W1)
+        if u8 is None:
+            assert x.C == 4 and x.buf.ld == 4 and x.coff == 0
+            H, W = x.H, x.W
+            op = self._base(L.OP_YSTEM, x, a_out, H // 2, W // 2)
+        else:
+            # u8 = (H, W, frame_h, frame_w, ext_index): the H x W canvas is never materialised; the op reads the frames
+            # (external buffers ext_index .. ext_index + 2: frames, tap tables, LUT) through fp_plan_run_ext
+            assert x is None
+            H, W, fh, fw, ext_index = u8
+            op = L.FpOp()
+            op.kind, op.N, op.H, op.W, op.OH, op.OW = L.OP_YSTEM_U8, self.N, H, W, H // 2, W // 2
+            op.Cin, op.in_ld, op.in_ns, op.in_off = 3, 3, fh * fw * 3, ext_index
+            op.out_ld, op.out_ns, op.out_off, op.out_cmul = a_out.buf.ld, a_out.buf.ns, a_out.buf.off + a_out.coff, 1
+            op.w_off = op.scale_off = op.bias_off = op.slope_off = -1
+        H1, W1 = H // 2, W // 2
+        assert H % 4 == 0 and W % 4 == 0 and (a_out.H, a_out.W) == (H1, W1) and (pool_out.H, pool_out.W) == (H1 // 2, W1 // 2)
         op.Cout = a_out.C
         op.KH = op.KW = 3
         op.stride = 2
@@ -328,7 +340,7 @@ class PlanBuilder:
         op.res_ld, op.res_ns = pool_out.buf.ld, pool_out.buf.ns
         op.res_off = pool_out.buf.off + pool_out.coff
         op.res_C = cpad(c1)
-        op.res_H, op.res_W = pool_out.H, pool_out.W
+        op.res_H, op.res_W = (pool_out.H, pool_out.W) if u8 is None else (u8[2], u8[3])
         op.w_off = self.add_weight(pack_conv_weight(w1, 4, cpad(c1)))
         if scale1 is not None:
             op.scale_off = self.add_weight(pad_vec(scale1, 32, 0.0))
@@ -341,7 +353,7 @@ class PlanBuilder:
                 pad_vec(bias2, nb2 * 16, 0.0)]
         op.slope_off = self.add_weight(np.concatenate(blob))
         self.ops.append(op)
-        self.alg_bytes.append(4 * self.N * (x.H * x.W * 3 + H1 * W1 * c1 + H1 * W1 * c1 + H1 * W1 * c2))
+        self.alg_bytes.append(4 * self.N * (H * W * 3 + H1 * W1 * c1 + H1 * W1 * c1 + H1 * W1 * c2))
         return a_out
 
     def maxpool(self, x, out, k, stride, pad):
@@ -454,12 +466,22 @@ class CompiledPlan:
         return self.arena[buf.off: buf.off + N * buf.ns].view(N, buf.H, buf.W, buf.C)
 
     _timing = None   # (timer, mask) set by bench.py around a timed step; None = plain fp_plan_run
+    _ext = None      # ctypes array of fp_ext (external buffers of *_U8 ops), set by set_ext()
+    _ext_keep = ()   # the tensors behind it, kept alive
+
+    def set_ext(self, tensors):
+        """External device buffers of the plan (e.g. [frames u8, tap tables, LUT] for a *_U8 stem op), in the order the
+        ops index them.  The tensors are held until the next set_ext."""
+        self._ext_keep = tuple(tensors)
+        self._ext = (L.FpExt * max(len(tensors), 1))(*[L.FpExt(t.data_ptr(), t.numel() * t.element_size())
+                                                      for t in tensors])
 
     def run(self):
         if self._timing is not None:
             return self.run_timed(*self._timing)
-        rc = self.lib.fp_plan_run(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
-                                  L.ptr(self.arena), self.arena_floats, L.current_stream(self.device))
+        rc = self.lib.fp_plan_run_ext(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
+                                      L.ptr(self.arena), self.arena_floats, self._ext, len(self._ext_keep),
+                                      L.current_stream(self.device))
         L.check(rc, "fp_plan_run")
 
     # ---- measurement support (bench.py) ----
@@ -471,8 +493,9 @@ class CompiledPlan:
     def run_timed(self, timer, mask):
         """Like run(), with HIP events recorded on the stream around the ops selected by mask (bytes, n_ops)."""
         m = (C.c_ubyte * self.n_ops)(*mask)
-        rc = self.lib.fp_plan_run_timed(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
-                                        L.ptr(self.arena), self.arena_floats, L.current_stream(self.device), timer, m)
+        rc = self.lib.fp_plan_run_timed_ext(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),
+                                            L.ptr(self.arena), self.arena_floats, self._ext, len(self._ext_keep),
+                                            L.current_stream(self.device), timer, m)
         L.check(rc, "fp_plan_run_timed")
 
     def accumulate(self, timer, ms):

@@ -57,8 +57,10 @@ enum fp_op_kind {
   FP_OP_L2NORM = 6,     /* out[m,:] = in[m,:] / ||in[m,:]||_2 over Cin channels (mobile_facenet.py:30-33) */
   FP_OP_BLAZEBLOCK = 7, /* fused BlazeBlock: dw3x3 -> 1x1 -> (+shortcut) -> ReLU (blazeface.py:12-47) */
   FP_OP_DWPW = 8,       /* fused Depth_Wise tail: dw3x3(+BN,+PReLU) -> 1x1(+BN) [+x] (mobile_facenet.py:72-85) */
-  FP_OP_YSTEM = 9       /* head of YOLOv5-face's StemBlock (y5/models/common.py:58-73): stem_1 (3x3 s2, SiLU) kept in LDS ->
+  FP_OP_YSTEM = 9,      /* head of YOLOv5-face's StemBlock (y5/models/common.py:58-73): stem_1 (3x3 s2, SiLU) kept in LDS ->
                            stem_2a (1x1, SiLU) -> out, and maxpool2x2(stem_1) -> res view (the concat half stem_3 reads) */
+  FP_OP_YSTEM_U8 = 10   /* FP_OP_YSTEM reading the u8 frames directly: the letterbox (fp_resize_normalize's arithmetic through
+                           fp_letterbox_tables) happens while the input tile is staged; needs fp_plan_run_ext */
 };
 
 enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
@@ -120,6 +122,10 @@ typedef struct fp_op {
  *            w_off -> stem_1 packed as CONV (K = 36 -> 40, Npad = 32), scale_off (-1 = none) / bias_off -> [32];
  *            slope_off -> stem_2a: [2][4][NB2*16][4] with element e of (j, g, n) = W[n][16j + 4g + e] (NB2 =
  *            ceil(Cout/16), zero padded), then [NB2*16] scale, [NB2*16] bias.  Both convs end in SiLU.
+ *   YSTEM_U8 : as YSTEM, but the input is EXTERNAL: in_off = index e into the ext[] array of fp_plan_run_ext with
+ *            ext[e] = frames [N][fh][fw][3] u8, ext[e+1] = the tap tables fp_letterbox_tables wrote for an H x W canvas
+ *            ((W + H + 1) x 8 bytes, W + H <= 2048), ext[e+2] = 256-float normalisation LUT.  H, W = the canvas (model input) size,
+ *            Cin = 3, res_H = fh, res_W = fw (the pooled map is OH/2 x OW/2 as for YSTEM).
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */
@@ -127,6 +133,21 @@ int fp_plan_run(const fp_op* ops /*host*/, int n_ops,
                 const float* weights, size_t weight_floats,
                 float* arena, size_t arena_floats,
                 void* stream);
+
+/*
+ * External buffers of a plan: device memory that is not part of the arena (the u8 frames a *_U8 op reads, its tap
+ * tables and LUT).  fp_plan_run_ext = fp_plan_run with such buffers; ops that need them fail with FP_ERR_INVALID_ARG
+ * under plain fp_plan_run.
+ */
+typedef struct fp_ext {
+  const void* ptr;   /* device pointer */
+  size_t bytes;      /* extent the library may read */
+} fp_ext;
+
+int fp_plan_run_ext(const fp_op* ops /*host*/, int n_ops,
+                    const float* weights, size_t weight_floats,
+                    float* arena, size_t arena_floats,
+                    const fp_ext* ext /*host*/, int n_ext, void* stream);
 
 /* Validation only (no GPU needed): same checks as fp_plan_run. */
 int fp_plan_validate(const fp_op* ops /*host*/, int n_ops, size_t weight_floats, size_t arena_floats);
@@ -143,6 +164,11 @@ int fp_plan_run_timed(const fp_op* ops /*host*/, int n_ops,
                       const float* weights, size_t weight_floats,
                       float* arena, size_t arena_floats,
                       void* stream, void* timer, const unsigned char* op_mask /*host, n_ops*/);
+int fp_plan_run_timed_ext(const fp_op* ops /*host*/, int n_ops,
+                          const float* weights, size_t weight_floats,
+                          float* arena, size_t arena_floats,
+                          const fp_ext* ext /*host*/, int n_ext,
+                          void* stream, void* timer, const unsigned char* op_mask /*host, n_ops*/);
 int fp_timer_accumulate(void* timer, float* ms_accum /*host, n_ops*/, int n_ops);
 /* Name of the HIP kernel family an op launches (as rocprofv3's kernel trace shows it); thread-local buffer. */
 const char* fp_op_kernel_name(const fp_op* op /*host*/);
@@ -178,6 +204,17 @@ int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int fr
                         const fp_resize_item* items /*device*/, int n_items,
                         float* canvas, int canvas_h, int canvas_w, int canvas_c /* >=3, extra channels zeroed */,
                         const float* lut256 /*device, 256 floats*/, int pad_value, int swap_rb,
+                        void* stream);
+
+/*
+ * Tap tables of ONE resize geometry, for the network stems that read u8 frames themselves (FP_OP_YSTEM_U8,
+ * FP_OP_STEM_U8): source rectangle (sx, sy, sw, sh) of a frame_h x frame_w frame -> destination rectangle
+ * (dx, dy, dw, dh) of a canvas_h x canvas_w canvas, everything else pad_value.  Same arithmetic as
+ * fp_resize_normalize (pad_resize_image, fde/modules/utils/image.py:31-59), evaluated once per column and row:
+ * tables = (canvas_w + canvas_h + 1) entries of 2 int32 (layout: csrc/letterbox.h); frame_h <= 65535.
+ */
+int fp_letterbox_tables(int frame_h, int frame_w, int canvas_h, int canvas_w, int sx, int sy, int sw, int sh,
+                        int dx, int dy, int dw, int dh, int pad_value, int swap_rb, int32_t* tables /*device*/,
                         void* stream);
 
 /*

@@ -482,6 +482,28 @@ def test_yolo_stem_fused_kernel_matches_unfused_ops(dev, c, hw, fuse_bn):
     assert rel_err(outs[True], outs[False]) < 2e-6
 
 
+@pytest.mark.parametrize("frame_hw", [(576, 1024), (360, 640), (97, 33), (640, 640), (1275, 1650)])
+def test_yolo_letterbox_fused_into_stem_is_bit_exact(dev, frame_hw):
+    """FP_OP_YSTEM_U8 (the stem reads the u8 frames through fp_letterbox_tables; no fp32 canvas) against the stand-alone
+    letterbox kernel + FP_OP_YSTEM: same fixed-point resize, same MFMA order -> identical decoded predictions; the
+    stand-alone kernel itself is checked against the oracle's pad_resize_image in test_resize_normalize_vs_oracle."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import preprocess_batch
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    rng = np.random.default_rng(frame_hw[0])
+    frames = torch.from_numpy(rng.integers(0, 256, (3,) + frame_hw + (3,), dtype=np.uint8)).to(dev)
+    m = _yolo("yolov5n-0.5", dev, 5, True)
+    zs = {}
+    for flag in (True, False):
+        Y.Model.FUSE_LETTERBOX = flag
+        try:
+            plan = preprocess_batch(m, frames, (256, 320))
+            assert (plan.input is None) == flag
+            zs[flag] = m.run_plan(plan).clone().cpu().numpy()
+        finally:
+            Y.Model.FUSE_LETTERBOX = True
+    np.testing.assert_array_equal(zs[True], zs[False])
+
+
 def test_yolo_concat_in_place_matches_copies(dev):
     """Concat inputs produced straight into the concat buffer (Model._emit) vs explicit copies: identical outputs."""
     from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
