@@ -149,6 +149,10 @@ const char* fp_op_kernel_name(const fp_op* op) {
         snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
         return buf;
       }
+      if (fp_conv3_eligible(*op)) {
+        snprintf(buf, sizeof(buf), "conv3_kernel<%d, %d>", fp_conv3_nb(*op), op->stride);
+        return buf;
+      }
       int nb, vec, pwd;
       fp_conv_variant(*op, &nb, &vec, &pwd);
       snprintf(buf, sizeof(buf), "conv_igemm_kernel<%d, %s, %s>", nb, vec ? "true" : "false", pwd ? "true" : "false");

@@ -504,6 +504,53 @@ def test_yolo_letterbox_fused_into_stem_is_bit_exact(dev, frame_hw):
     np.testing.assert_array_equal(zs[True], zs[False])
 
 
+@pytest.mark.parametrize("cin,cout,hw,stride,res,n", [
+    (64, 64, (40, 40), 1, True, 24),      # Bottleneck.cv2 with the shortcut (yolov5n C3)
+    (92, 92, (33, 37), 1, False, 24),     # odd k-quad count in the last slab, ragged 8 x 16 tiles
+    (96, 184, (40, 40), 1, False, 24),    # two 128-column chunks (the second one partial)
+    (24, 24, (32, 48), 1, True, 24),      # single n tile: two alternating partial sums
+    (128, 128, (64, 72), 2, False, 24),   # stride 2: even / odd column planes
+    (132, 96, (66, 70), 2, False, 24),    # stride 2, last slab of one k-quad, ragged tiles
+])
+def test_conv3_lds_image_kernel_vs_torch(dev, cin, cout, hw, stride, res, n):
+    """csrc/conv3.hip (3x3 conv with the A operand read from an LDS image) against torch-CPU conv2d + SiLU
+    (+ Bottleneck shortcut, y5/models/common.py:76-87), writing into a channel slice of a wider buffer."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(cin + cout)
+    H, W = hw
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = rng.normal(0, 1, (n, cin, H, W)).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (cout, cin, 3, 3)).astype(np.float32)
+    b = rng.normal(0, 0.1, (cout,)).astype(np.float32)
+    sc = rng.uniform(0.8, 1.2, (cout,)).astype(np.float32)
+    pb = PlanBuilder(n)
+    xin = pb.new_buf(H, W, cin + 8)                       # input is a channel slice too (in_ld > Cin)
+    out = pb.new_buf(OH, OW, cout + 12)
+    from face_detection_and_recognition_amd.plan import View
+    xv = View(xin, 4, cin)
+    kw = dict(stride=stride, pad=(1, 1), scale=sc, bias=b, act=L.ACT_SILU)
+    if res:
+        assert stride == 1 and cin == cout
+        kw.update(res=xv, res_mode=L.RES_ADD_AFTER_ACT)
+    pb.conv(xv, w, View(out, 8, cout), **kw)
+    plan = CompiledPlan(pb, dev)
+    assert plan.kernel_name(0).startswith("conv3_kernel"), plan.kernel_name(0)
+    plan.arena.zero_()
+    plan.buf_tensor(xin, n)[..., 4:4 + cin].copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    got = plan.buf_tensor(out, n)[..., 8:8 + cout].permute(0, 3, 1, 2).cpu().numpy()
+    with torch.no_grad():
+        y = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride=stride, padding=1)
+        y = F.silu(y * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(b).view(1, -1, 1, 1))
+        if res:
+            y = y + torch.from_numpy(x)
+    assert rel_err(got, y.numpy()) < 2e-6
+    # nothing outside the slice was written
+    full = plan.buf_tensor(out, n).cpu().numpy()
+    assert np.all(full[..., :8] == 0) and np.all(full[..., 8 + cout:] == 0)
+
+
 def test_yolo_concat_in_place_matches_copies(dev):
     """Concat inputs produced straight into the concat buffer (Model._emit) vs explicit copies: identical outputs."""
     from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
