@@ -193,7 +193,7 @@ def run_pipeline(args):
     # ---- per-op timers for the roofline figures ----
     # HIP events around an op cost a little, so: one un-timed probe pass over the batches with events on every op
     # finds the dominant kernel family; the timed steps then carry events only on that family's launches.
-    det_plan = det.net.plan_for(B_FRAMES)
+    det_plan = det.net.last_plan
     emb_plans = list(emb._plans._plans.values())
     plans = [det_plan] + emb_plans
     fam_ms = {}

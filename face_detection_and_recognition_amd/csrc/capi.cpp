@@ -40,7 +40,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const bool spatial = op.kind != FP_OP_L2NORM && op.kind != FP_OP_COPY;
   const int OH = spatial ? op.OH : op.H, OW = spatial ? op.OW : op.W;
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
-  const bool ext_in = op.kind == FP_OP_YSTEM_U8;      // input lives in an external buffer (checked at launch)
+  const bool ext_in = op.kind == FP_OP_YSTEM_U8 || op.kind == FP_OP_STEM_U8;   // input in an external buffer (checked at launch)
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
                     op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
@@ -61,10 +61,10 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
       return FP_ERR_INVALID_ARG;
   }
-  if (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK) {
+  if (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_STEM_U8) {
     int64_t wext;
-    if (op.kind == FP_OP_CONV) {
-      const int64_t K = (int64_t)op.KH * op.KW * op.Cin;
+    if (op.kind != FP_OP_BLAZEBLOCK) {
+      const int64_t K = (int64_t)op.KH * op.KW * (op.kind == FP_OP_STEM_U8 ? 4 : op.Cin);
       wext = ((K + 7) / 8 * 8) * ((op.Cout + 31) / 32 * 32);
     } else {
       // BLAZEBLOCK: dw weights [9][Cin] followed (separately addressed) by the packed 1x1; w_off addresses the
@@ -100,7 +100,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     const int64_t res_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)(op.OH / 2) * (op.OW / 2) - 1) * op.res_ld + op.res_C;
     if (!span_ok(op.res_off, res_ext, arena_floats)) return FP_ERR_BOUNDS;
   }
-  if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV) {
+  if (op.kind == FP_OP_STEM_U8 && (op.Cin != 3 || op.res_H <= 0 || op.res_W < 3 || !fp_stem_u8_shape_ok(op)))
+    return FP_ERR_UNSUPPORTED;
+  if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_STEM_U8) {
     if (op.scale_off >= 0 && !span_ok(op.scale_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
     if (op.bias_off >= 0 && !span_ok(op.bias_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
     if (op.slope_off >= 0 && !span_ok(op.slope_off, Cout, weight_floats)) return FP_ERR_BOUNDS;
@@ -132,6 +134,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_DWPW:
     case FP_OP_YSTEM:
     case FP_OP_YSTEM_U8:
+    case FP_OP_STEM_U8:
       return FP_OK;
     default:
       return FP_ERR_UNSUPPORTED;
@@ -146,7 +149,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
     case FP_OP_CONV: {
       if (fp_pws_eligible(*op)) { snprintf(buf, sizeof(buf), "pws_kernel<%d, %d>", op->Cin, op->Cin == 64 ? 12 : 8); return buf; }
       if (fp_stem_eligible(*op)) {
-        snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
+        snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d, false>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
         return buf;
       }
       if (fp_conv3_eligible(*op)) {
@@ -183,6 +186,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;
+    case FP_OP_STEM_U8:
+      snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d, true>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
+      return buf;
     case FP_OP_YSTEM:
     case FP_OP_YSTEM_U8:
       snprintf(buf, sizeof(buf), "ystem_kernel<%d, %s>", fp_ystem_nb2(*op), op->kind == FP_OP_YSTEM_U8 ? "true" : "false");
@@ -212,6 +218,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);
+    case FP_OP_STEM_U8: return fp_launch_stem_u8(op, weights, arena, ext, n_ext, s);
     default: return FP_ERR_UNSUPPORTED;
   }
 }

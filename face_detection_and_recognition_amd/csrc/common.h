@@ -54,6 +54,8 @@ bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take 
 int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)
 int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_stem_u8_shape_ok(const fp_op& op);
+int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s);
 int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 int fp_ystem_nb2(const fp_op& op);
 int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s);

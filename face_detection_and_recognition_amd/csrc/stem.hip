@@ -16,6 +16,7 @@
 // k order and the packed weights are conv.hip's (k = tap*4 + c, zero rows up to Kpad): same products in the same
 // order, identical results.
 #include "common.h"
+#include "letterbox.h"
 
 namespace {
 
@@ -28,12 +29,17 @@ struct StemArgs {
   const float* slope;
   int H, W, OH, OW, OHW, Cout, Npad, Kpad, act, pad_t, pad_l, Wp, rows_max, tiles_per_img, ntiles;
   long in_ns;
+  // U8 input: the H x W image is a letterbox canvas resampled from u8 frames while it is staged (letterbox.h)
+  const uint8_t* frames;
+  const fp_lb_tap* tabs;     // [W] column taps, [H] row taps, trailer {pad colour, swap R/B}
+  const float* lut;
+  long frame_bytes, row_bytes;
 };
 
 constexpr int TMS = 128;
 constexpr int PF = 6;   // staged float4s per lane and tile (rows_max * Wp <= PF * 256, checked on the host)
 
-template <int KS, int NB>
+template <int KS, int NB, bool U8>
 __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
   constexpr int BN = NB * 32;
   constexpr int NTAP = KS * KS;
@@ -41,10 +47,21 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
   float* Img = smem;                                   // [rows_max][Wp][4]
   float* Bs = Img + p.rows_max * p.Wp * 4;             // [Kpad/4][BN][4]
   float* Ot = Bs + p.Kpad * BN;                        // [128][Cout]
+  float* LutS = Ot + TMS * p.Cout;                     // U8: [256] normalisation LUT
+  fp_lb_tap* TabS = (fp_lb_tap*)(LutS + 256);          // U8: [W + H] tap tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
+  int pad_value = 0, swap_rb = 0;
+  if (U8) {
+    LutS[tid] = p.lut[tid];
+    for (int i = tid; i < p.W + p.H; i += 256) TabS[i] = p.tabs[i];
+    const fp_lb_tap tr = p.tabs[p.W + p.H];
+    pad_value = tr.a;
+    swap_rb = tr.b;
+    __syncthreads();
+  }
   // weights -> LDS once (the packed blob is [Kpad/4][Npad][4] with Npad == BN)
   for (int i = tid; i < (p.Kpad >> 2) * BN; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.w + (long)i * 4);
   float sc[NB], bi[NB], sl[NB];
@@ -65,7 +82,9 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
   }
 
   // staging of a tile's image rows: lane -> float4 slots tid + 256*j of the [nrows][Wp] image
-  f32x4 pre[PF];
+  f32x4 pre[U8 ? 1 : PF];
+  fp_lb_raw raw[U8 ? PF : 1];
+  fp_lb_tap xt[U8 ? PF : 1], yt[U8 ? PF : 1];
   unsigned premask = 0;
   int srow[PF], sxp[PF];   // slot -> (row, column) of the staged image: the same for every tile
 #pragma unroll
@@ -79,14 +98,21 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
     const int m_lo = tin * TMS, m_hi = min(m_lo + TMS, p.OHW) - 1;
     const int oy_lo = m_lo / p.OW, oy_hi = m_hi / p.OW;
     const int iy_lo = oy_lo * 2 - p.pad_t, nslots = ((oy_hi - oy_lo) * 2 + KS) * p.Wp;
-    const float* ib = p.in + (long)img * p.in_ns;
+    const float* ib = U8 ? nullptr : p.in + (long)img * p.in_ns;
     premask = 0;
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int i = tid + 256 * j;
       const int iy = iy_lo + srow[j], ix = sxp[j] - p.pad_l;
       const bool ok = i < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      pre[j] = *(const f32x4*)(ib + ((long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)) * 4);
+      const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+      if (U8) {
+        xt[j] = TabS[cx];
+        yt[j] = TabS[p.W + cy];
+        raw[j] = fp_lb_issue(p.frames + (long)img * p.frame_bytes, p.row_bytes, xt[j], yt[j]);
+      } else {
+        pre[j] = *(const f32x4*)(ib + ((long)cy * p.W + cx) * 4);
+      }
       if (ok) premask |= 1u << j;
     }
   };
@@ -95,7 +121,10 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int i = tid + 256 * j;
-      if (i < p.rows_max * p.Wp) *(f32x4*)&Img[i * 4] = ((premask >> j) & 1u) ? pre[j] : z4;
+      f32x4 v;
+      if (U8) v = fp_lb_finish(raw[j], xt[j], yt[j], LutS, pad_value, swap_rb);
+      else v = pre[j];
+      if (i < p.rows_max * p.Wp) *(f32x4*)&Img[i * 4] = ((premask >> j) & 1u) ? v : z4;
     }
   };
 
@@ -162,8 +191,9 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
   }
 }
 
-size_t stem_lds_bytes(int rows_max, int Wp, int Kpad, int Npad, int Cout) {
-  return 4 * ((size_t)rows_max * Wp * 4 + (size_t)Kpad * Npad + (size_t)TMS * Cout);
+size_t stem_lds_bytes(int rows_max, int Wp, int Kpad, int Npad, int Cout, int table_entries = 0) {
+  return 4 * ((size_t)rows_max * Wp * 4 + (size_t)Kpad * Npad + (size_t)TMS * Cout) +
+         (table_entries ? 1024 + 8 * (size_t)table_entries : 0);
 }
 
 }  // namespace
@@ -182,11 +212,9 @@ static void stem_geometry(const fp_op& op, int* Wp, int* rows_max) {
   *rows_max = (rows_touched - 1) * 2 + op.KH;
 }
 
-// KxK (3 or 5) stride-2 conv on a dense 4-float-pixel image into a dense NHWC tensor, Cout <= 64, no residual,
-// activation none / ReLU / PReLU.  Everything else stays with conv_igemm_kernel.
-bool fp_stem_eligible(const fp_op& op) {
-  if (op.kind != FP_OP_CONV || op.KH != op.KW || (op.KH != 3 && op.KH != 5) || op.stride != 2) return false;
-  if (op.Cin != 4 || op.in_ld != 4 || op.in_ns != (int64_t)op.H * op.W * 4 || op.in_off % 4) return false;
+// shape conditions shared by the fp32-image and the u8-frame forms
+static bool stem_shape_ok(const fp_op& op, int table_entries) {
+  if (op.KH != op.KW || (op.KH != 3 && op.KH != 5) || op.stride != 2) return false;
   if (op.out_cmul != 1 || op.out_ld != op.Cout || op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return false;
   if (op.Cout % 4 || op.Cout <= 0 || op.Cout > 64 || op.out_off % 4 || op.w_off % 4) return false;
   if (op.res_mode != FP_RES_NONE) return false;
@@ -194,17 +222,24 @@ bool fp_stem_eligible(const fp_op& op) {
   if (op.act == FP_ACT_PRELU && op.slope_off < 0) return false;
   if (op.pad_t < 0 || op.pad_l < 0 || op.pad_t >= op.KH || op.pad_l >= op.KW) return false;
   if (op.OH <= 0 || op.OW <= 0 || (op.OH - 1) * 2 - op.pad_t >= op.H || (op.OW - 1) * 2 - op.pad_l >= op.W) return false;
-  if ((long)op.N * op.OH * op.OW < 1024L * TMS) return false;     // small batches: one tile per workgroup is fine
   int Wp, rows_max;
   stem_geometry(op, &Wp, &rows_max);
   if ((long)rows_max * Wp > PF * 256) return false;
   const int Kpad = (int)fp_round_up(op.KH * op.KW * 4, 8), Npad = (int)fp_round_up(op.Cout, 32);
-  return stem_lds_bytes(rows_max, Wp, Kpad, Npad, op.Cout) <= 64 * 1024;
+  return stem_lds_bytes(rows_max, Wp, Kpad, Npad, op.Cout, table_entries) <= (table_entries ? 80 : 64) * 1024;
 }
 
-int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
-  StemArgs a;
-  a.in = arena + op.in_off;
+// KxK (3 or 5) stride-2 conv on a dense 4-float-pixel image into a dense NHWC tensor, Cout <= 64, no residual,
+// activation none / ReLU / PReLU.  Everything else stays with conv_igemm_kernel.
+bool fp_stem_eligible(const fp_op& op) {
+  if (op.kind != FP_OP_CONV) return false;
+  if (op.Cin != 4 || op.in_ld != 4 || op.in_ns != (int64_t)op.H * op.W * 4 || op.in_off % 4) return false;
+  if ((long)op.N * op.OH * op.OW < 1024L * TMS) return false;     // small batches: one tile per workgroup is fine
+  return stem_shape_ok(op, 0);
+}
+
+static void stem_fill(const fp_op& op, const float* weights, float* arena, StemArgs& a) {
+  a.in = nullptr;
   a.out = arena + op.out_off;
   a.w = weights + op.w_off;
   a.scale = op.scale_off >= 0 ? weights + op.scale_off : nullptr;
@@ -218,17 +253,65 @@ int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStrea
   a.tiles_per_img = fp_ceil_div(a.OHW, TMS);
   a.ntiles = op.N * a.tiles_per_img;
   a.in_ns = op.in_ns;
-  const size_t lds = stem_lds_bytes(a.rows_max, a.Wp, a.Kpad, a.Npad, op.Cout);
+  a.frames = nullptr; a.tabs = nullptr; a.lut = nullptr;
+  a.frame_bytes = a.row_bytes = 0;
+}
+
+template <bool U8>
+static int stem_launch(const fp_op& op, const StemArgs& a, hipStream_t s) {
+  const size_t lds = stem_lds_bytes(a.rows_max, a.Wp, a.Kpad, a.Npad, op.Cout, U8 ? op.H + op.W : 0);
   int per_cu = (int)(160 * 1024 / lds);   // resident workgroups per CU by LDS (registers allow 3)
-  per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+  const int cap = 3;
+  per_cu = per_cu > cap ? cap : (per_cu < 1 ? 1 : per_cu);
   int grid = 256 * per_cu;
   if (grid > a.ntiles) grid = a.ntiles;
   const int NB = a.Npad / 32;
-  if (op.KH == 3 && NB == 1) hipLaunchKernelGGL((stem_conv_kernel<3, 1>), dim3(grid), dim3(256), lds, s, a);
-  else if (op.KH == 3 && NB == 2) hipLaunchKernelGGL((stem_conv_kernel<3, 2>), dim3(grid), dim3(256), lds, s, a);
-  else if (op.KH == 5 && NB == 1) hipLaunchKernelGGL((stem_conv_kernel<5, 1>), dim3(grid), dim3(256), lds, s, a);
-  else if (op.KH == 5 && NB == 2) hipLaunchKernelGGL((stem_conv_kernel<5, 2>), dim3(grid), dim3(256), lds, s, a);
+  hipError_t ae = hipSuccess;
+#define FP_STEM_CASE(KSV, NBV)                                                                                       \
+  {                                                                                                                  \
+    if (lds > 64 * 1024)                                                                                             \
+      ae = hipFuncSetAttribute((const void*)stem_conv_kernel<KSV, NBV, U8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)lds);                                                                            \
+    if (ae == hipSuccess) hipLaunchKernelGGL((stem_conv_kernel<KSV, NBV, U8>), dim3(grid), dim3(256), lds, s, a);    \
+  }
+  if (op.KH == 3 && NB == 1) FP_STEM_CASE(3, 1)
+  else if (op.KH == 3 && NB == 2) FP_STEM_CASE(3, 2)
+  else if (op.KH == 5 && NB == 1) FP_STEM_CASE(5, 1)
+  else if (op.KH == 5 && NB == 2) FP_STEM_CASE(5, 2)
   else return FP_ERR_UNSUPPORTED;
+#undef FP_STEM_CASE
+  if (ae != hipSuccess) {
+    fp_set_hip_error(ae);
+    return FP_ERR_LAUNCH;
+  }
   FP_CHECK_LAUNCH();
   return FP_OK;
+}
+
+int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  StemArgs a;
+  stem_fill(op, weights, arena, a);
+  a.in = arena + op.in_off;
+  return stem_launch<false>(op, a, s);
+}
+
+// FP_OP_STEM_U8 (include/facepath.h): the same conv with the H x W input resampled from u8 frames while it is staged.
+bool fp_stem_u8_shape_ok(const fp_op& op) { return op.H + op.W <= 2048 && stem_shape_ok(op, op.H + op.W); }
+
+int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s) {
+  const long e = op.in_off;
+  if (e < 0 || e + 2 >= n_ext || !ext) return FP_ERR_INVALID_ARG;
+  const int fh = op.res_H, fw = op.res_W;
+  if (op.Cin != 3 || fh <= 0 || fw < 3 || !fp_stem_u8_shape_ok(op)) return FP_ERR_UNSUPPORTED;
+  if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 1) * 8 ||
+      ext[e + 2].bytes < 256 * sizeof(float) || !ext[e].ptr || !ext[e + 1].ptr || !ext[e + 2].ptr)
+    return FP_ERR_BOUNDS;
+  StemArgs a;
+  stem_fill(op, weights, arena, a);
+  a.frames = (const uint8_t*)ext[e].ptr;
+  a.tabs = (const fp_lb_tap*)ext[e + 1].ptr;
+  a.lut = (const float*)ext[e + 2].ptr;
+  a.row_bytes = (long)fw * 3;
+  a.frame_bytes = (long)fh * fw * 3;
+  return stem_launch<true>(op, a, s);
 }

@@ -169,16 +169,24 @@ class BlazeFace(nn.Module):
     def input_hw(self):
         return (256, 256) if self.back_model else (128, 128)
 
-    def _emit(self, N):
-        """Emit the op list for batch N (host only, no GPU needed)."""
+    FUSE_LETTERBOX = True    # class-wide switch: False keeps the stand-alone letterbox kernel (A/B parity tests)
+
+    def _emit(self, N, frame_hw=None):
+        """Emit the op list for batch N (host only, no GPU needed).  frame_hw = (frame_h, frame_w): the stem reads u8
+        frames of that size itself (FP_OP_STEM_U8: no fp32 canvas, no letterbox launch; external buffers 0..2 =
+        frames, tap tables, LUT); None: the plan input is the NHWC fp32 canvas."""
         H, W = self.input_hw
         pb = PlanBuilder(N)
-        inp = pb.new_buf(H, W, 3)                    # NHWC, channel-padded to 4
+        inp = pb.new_buf(H, W, 3) if frame_hw is None else None      # NHWC, channel-padded to 4
         seq = list(self.backbone) if self.back_model else list(self.backbone1)
         stem = seq[0]
         # F.pad(x, (1, 2, 1, 2)) + 5x5 stride-2 conv + ReLU (blazeface.py:118-120,195)
         x = pb.new_buf(H // 2, W // 2, 24)
-        pb.conv(inp.view(), npy(stem.weight), x.view(), stride=2, pad=(1, 1), bias=npy(stem.bias), act=L.ACT_RELU)
+        if frame_hw is None:
+            pb.conv(inp.view(), npy(stem.weight), x.view(), stride=2, pad=(1, 1), bias=npy(stem.bias), act=L.ACT_RELU)
+        else:
+            pb.stem_u8((H, W, frame_hw[0], frame_hw[1], 0), npy(stem.weight), x.view(), pad=(1, 1), bias=npy(stem.bias),
+                       act=L.ACT_RELU)
         for blk in seq[2:]:
             y = blk.emit(pb, x.view())
             pb.free(x)
@@ -207,20 +215,21 @@ class BlazeFace(nn.Module):
         head(h, self.regressor_16, r_off, A * 16, 512, 16)
         return pb, inp, r_off, c_off
 
-    def _build(self, N, cache=None):
+    def _build(self, N, cache=None, frame_hw=None):
         A = self.num_anchors
-        pb, inp, r_off, c_off = self._emit(N)
+        pb, inp, r_off, c_off = self._emit(N, frame_hw)
         plan = CompiledPlan(pb, self._device(), cache)
         plan.inp = inp
         plan.r = plan.arena[r_off: r_off + N * A * 16].view(N, A, 16)
         plan.c = plan.arena[c_off: c_off + N * A].view(N, A, 1)
-        plan.input = plan.buf_tensor(inp, N)
+        plan.input = plan.buf_tensor(inp, N) if inp is not None else None
+        plan.frame_hw, plan.canvas_hw, plan.tables = frame_hw, self.input_hw, None
         return plan
 
-    def plan_for(self, N):
+    def plan_for(self, N, frame_hw=None):
         if self._device().type != "cuda":
             raise L.FacepathError("BlazeFace runs only on a HIP device (model.to('cuda')); there is no CPU path")
-        return self._plans.get(N, lambda cache: self._build(N, cache))
+        return self._plans.get((N, frame_hw), lambda cache: self._build(N, cache, frame_hw))
 
     # ------------------------------------------------------------------ inference
     def forward(self, x):

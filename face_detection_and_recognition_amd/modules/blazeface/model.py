@@ -7,7 +7,7 @@ import torch
 
 from ... import _lib as L
 from ..models.base import Model
-from ..utils.image import letterbox_batch
+from ..utils.image import bind_letterbox, letterbox_batch
 from .blazeface import BlazeFace, generate_anchors
 
 MODEL_IN_SIZES = {"back": (256, 256), "front": (128, 128)}
@@ -62,11 +62,17 @@ class BlazeFaceModel(Model):
         if isinstance(frames, np.ndarray):
             frames = torch.from_numpy(np.ascontiguousarray(frames))
         frames = frames.to(dev)
-        B = frames.shape[0]
-        plan = net.plan_for(B)
-        # pad_resize_image + BGR->RGB + x/127.5-1 in one kernel (model.py:61,75; blazeface.py:248-250)
-        letterbox_batch(frames, self.input_size, net._preprocess_lut(), plan.input, pad_value=125, swap_rb=True)
+        B, fh, fw, _ = frames.shape
+        if BlazeFace.FUSE_LETTERBOX and fw >= 3 and fh <= 65535 and frames.dtype == torch.uint8:
+            # pad_resize_image + BGR->RGB + x/127.5-1 (model.py:61,75; blazeface.py:248-250) happen inside the stem conv's
+            # staging (FP_OP_STEM_U8): no fp32 canvas, no letterbox launch
+            plan = net.plan_for(B, frame_hw=(fh, fw))
+            bind_letterbox(plan, frames.contiguous(), net._preprocess_lut(), pad_value=125, swap_rb=True)
+        else:
+            plan = net.plan_for(B)
+            letterbox_batch(frames, self.input_size, net._preprocess_lut(), plan.input, pad_value=125, swap_rb=True)
         plan.run()
+        net.last_plan = plan          # measurement / tests: the plan (and its raw r, c views) of the last batch
         return net.postprocess(plan.r, plan.c)
 
     def predict_batch(self, frames):

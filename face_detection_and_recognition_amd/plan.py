@@ -309,6 +309,36 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * G + opix * G + opix * G + opix * cout))
         return out
 
+    def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
+        """First conv of a network reading u8 frames itself (FP_OP_STEM_U8): KxK (3 or 5) stride 2, Cout <= 64, dense
+        output buffer.  u8 = (H, W, frame_h, frame_w, ext_index): the H x W letterbox canvas is resampled from the
+        frames while the conv's input tile is staged (external buffers ext_index..+2 = frames, tap tables, LUT).
+        w is the [Cout, 3, K, K] weight; it is packed for a 4-channel pixel like the fp32-canvas form."""
+        H, W, fh, fw, ext_index = u8
+        cout, cin, kh, kw = w.shape
+        assert cin == 3 and kh == kw and kh in (3, 5) and out.cmul == 1 and out.coff == 0 and out.buf.ld == out.C
+        assert out.C <= 64 and H + W <= 2048
+        op = L.FpOp()
+        op.kind, op.N, op.H, op.W, op.OH, op.OW = L.OP_STEM_U8, self.N, H, W, out.H, out.W
+        op.Cin, op.in_ld, op.in_ns, op.in_off = 3, 3, fh * fw * 3, ext_index
+        op.Cout, op.out_ld, op.out_ns, op.out_off, op.out_cmul = out.C, out.buf.ld, out.buf.ns, out.buf.off, 1
+        op.KH = op.KW = kh
+        op.stride = 2
+        op.pad_t, op.pad_l = pad
+        op.act = act
+        op.res_H, op.res_W = fh, fw
+        op.w_off = op.scale_off = op.bias_off = op.slope_off = -1
+        op.w_off = self.add_weight(pack_conv_weight(w, 4, out.C))
+        if scale is not None:
+            op.scale_off = self.add_weight(pad_vec(scale, out.C, 0.0))
+        if bias is not None:
+            op.bias_off = self.add_weight(pad_vec(bias, out.C, 0.0))
+        if slope is not None:
+            op.slope_off = self.add_weight(pad_vec(slope, out.C, 0.0))
+        self.ops.append(op)
+        self.alg_bytes.append(4 * self.N * (H * W * 3 + out.H * out.W * cout))
+        return out
+
     def ystem(self, x, w1, scale1, bias1, w2, scale2, bias2, a_out, pool_out, u8=None):
         """Head of YOLOv5-face's StemBlock (common.py:58-73) as ONE op: stem_1 (3x3 s2 p1, SiLU) stays in LDS,
         stem_2a (1x1, SiLU) -> a_out, maxpool2x2(stem_1) -> pool_out (a channel slice of stem_3's concat buffer).

@@ -59,8 +59,10 @@ enum fp_op_kind {
   FP_OP_DWPW = 8,       /* fused Depth_Wise tail: dw3x3(+BN,+PReLU) -> 1x1(+BN) [+x] (mobile_facenet.py:72-85) */
   FP_OP_YSTEM = 9,      /* head of YOLOv5-face's StemBlock (y5/models/common.py:58-73): stem_1 (3x3 s2, SiLU) kept in LDS ->
                            stem_2a (1x1, SiLU) -> out, and maxpool2x2(stem_1) -> res view (the concat half stem_3 reads) */
-  FP_OP_YSTEM_U8 = 10   /* FP_OP_YSTEM reading the u8 frames directly: the letterbox (fp_resize_normalize's arithmetic through
+  FP_OP_YSTEM_U8 = 10,  /* FP_OP_YSTEM reading the u8 frames directly: the letterbox (fp_resize_normalize's arithmetic through
                            fp_letterbox_tables) happens while the input tile is staged; needs fp_plan_run_ext */
+  FP_OP_STEM_U8 = 11    /* first conv of a network (KxK in {3,5}, stride 2, Cout <= 64, dense NHWC output; BlazeFace's stem,
+                           blazeface.py:118-120,195) reading the u8 frames the same way; needs fp_plan_run_ext */
 };
 
 enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
@@ -126,6 +128,9 @@ typedef struct fp_op {
  *            ext[e] = frames [N][fh][fw][3] u8, ext[e+1] = the tap tables fp_letterbox_tables wrote for an H x W canvas
  *            ((W + H + 1) x 8 bytes, W + H <= 2048), ext[e+2] = 256-float normalisation LUT.  H, W = the canvas (model input) size,
  *            Cin = 3, res_H = fh, res_W = fw (the pooled map is OH/2 x OW/2 as for YSTEM).
+ *   STEM_U8 : a CONV (weights packed for Cin = 4: k = tap*4 + c, zero fourth channel; scale / bias / slope / act as
+ *            CONV, no residual) whose H x W input is the letterbox canvas of external u8 frames: in_off = e with
+ *            ext[e .. e+2] = frames, tap tables, LUT as for YSTEM_U8; Cin = 3, res_H = fh, res_W = fw.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */
