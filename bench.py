@@ -105,7 +105,8 @@ def latest_pmc_traffic():
     The figures come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
     (gfx950: FETCH_SIZE doubled, MI355X_MICROARCH.md), summarised by tools/profile_summary.py -- they are NOT measured
     in this run, which is why the JSON line names the file."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json"))) or \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_traffic.json")))
     if not files:
         return None, {}
     try:

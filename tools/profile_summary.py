@@ -23,6 +23,7 @@ def short(name):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    cmd = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 10 --warmup 3 --no-cpu-baseline"
     os.makedirs("profiles", exist_ok=True)
     ks = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0]
     shutil.copy(ks, f"profiles/{tag}_kernel_stats.csv")
@@ -47,15 +48,15 @@ def main():
                           "hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024)}
     json.dump(traffic, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
     with open(f"profiles/{tag}_summary.md", "w") as o:
-        o.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`\n\n")
+        o.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 {cmd}`\n\n")
         o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
-        for r in stats[:14]:
+        for r in stats[:24]:
             o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
                     f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
         o.write("\nPMC (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, KiB, per launch average; "
                 "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the x2 being the gfx950 FETCH_SIZE correction):\n\n")
         o.write("| kernel | FETCH KiB | WRITE KiB | HBM MB / launch |\n|---|---|---|---|\n")
-        for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:10]:
+        for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:16]:
             o.write(f"| `{k}` | {v['FETCH_SIZE_KiB_avg']} | {v['WRITE_SIZE_KiB_avg']} | {v['hbm_bytes_per_launch'] / 1e6:.1f} |\n")
     print(open(f"profiles/{tag}_summary.md").read())
 
