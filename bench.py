@@ -124,9 +124,15 @@ def init_dist():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if os.environ.get("BENCH_SAME_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    # BENCH_FORCE_DIST=1: initialise the process group and run the exchange even with one rank (exercises RCCL itself
+    # on a one-GPU box; the timing of such a run is not a benchmark result)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -139,7 +145,7 @@ def init_dist():
 
 def reduce_time_and_count(elapsed, count, world, dist, dev, backend):
     """MAX of the elapsed time and SUM of the processed units over ranks."""
-    if world == 1:
+    if world == 1 or dist is None:
         return elapsed, float(count)
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -161,7 +167,8 @@ def run_pipeline(args):
     ref = W.make_reference(N_REF, dev)
     pipe = FacePipeline(det, emb, ref, tau=0.3)
     gather_block = n_dev = None
-    if world > 1:
+    multi = dist is not None
+    if multi:
         from face_detection_and_recognition_amd import distributed as D
         gather_block = torch.zeros((EMB_CAP_ROWS, emb.embedding_size), device=dev)
         n_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
@@ -172,7 +179,7 @@ def run_pipeline(args):
     def step(k):
         out = pipe.step(batches[k % N_BATCHES])
         n = out["n_faces"]
-        if world > 1:
+        if multi:
             if n > EMB_CAP_ROWS:
                 raise RuntimeError(f"{n} faces in one step exceed the all_gather block of {EMB_CAP_ROWS} rows")
             gather_block[:n].copy_(out["emb"])
@@ -216,7 +223,7 @@ def run_pipeline(args):
     masks = [bytes([1 if p.kernel_name(i) == dom else 0 for i in range(p.n_ops)]) for p in plans]
     timers = [[p.new_timer() for p in plans] for _ in range(args.steps)]
 
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -229,13 +236,13 @@ def run_pipeline(args):
         faces += n
         faces_per_step.append(n)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     t1 = time.perf_counter()
     for p in plans:
         p._timing = None
 
-    elapsed, faces_all = reduce_time_and_count(t1 - t0, faces, world, dist, dev, backend)
+    elapsed, faces_all = reduce_time_and_count(t1 - t0, faces, world if not multi else max(world, 2), dist, dev, backend)
 
     # ---- roofline of the dominant kernel family (rank 0) ----
     roof = None
@@ -302,7 +309,7 @@ def run_pipeline(args):
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
@@ -319,7 +326,7 @@ def run_c5(args):
     ginv = S.row_inv_norm(G)
 
     def step():
-        if world > 1:
+        if dist is not None:
             from face_detection_and_recognition_amd import distributed as Dm
             if backend == "nccl":
                 return Dm.sharded_cosine_filter(G, Rl, 0.3, lambda a, b, tau: S.cosine_filter(a, b, tau, ginv=ginv),
@@ -331,7 +338,7 @@ def run_c5(args):
 
     for _ in range(max(args.warmup, 1)):
         step()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -341,7 +348,7 @@ def run_c5(args):
         best, arg, keep = step()
         ev[k][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     nr = nr_local * world
@@ -363,7 +370,7 @@ def run_c5(args):
                                                       "events on torch's current stream (the launch stream)"},
                 "cpu_baseline": None}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
