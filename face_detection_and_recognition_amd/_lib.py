@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfacepath.so")
 
 FP_OK = 0
+ABI_VERSION = 2
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -36,6 +37,7 @@ class FpOp(C.Structure):
         ("in_ns", C.c_int64), ("out_ns", C.c_int64), ("res_ns", C.c_int64),
         ("in_off", C.c_int64), ("out_off", C.c_int64), ("res_off", C.c_int64),
         ("w_off", C.c_int64), ("scale_off", C.c_int64), ("bias_off", C.c_int64), ("slope_off", C.c_int64),
+        ("act2", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -115,8 +117,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     v = lib.fp_abi_version()
-    if v != 1:
-        raise FacepathError(f"libfacepath ABI version {v}, expected 1")
+    if v != ABI_VERSION:
+        raise FacepathError(f"libfacepath ABI version {v}, expected {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -48,7 +48,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
   if (!ext_in && !span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
   if (ext_in && op.in_off < 0) return FP_ERR_INVALID_ARG;
-  const int64_t out_ch = (op.kind == FP_OP_CONV && op.res_mode == FP_RES_SHUFFLE2) ? 2 * (int64_t)Cout : Cout;
+  const int64_t out_ch = ((op.kind == FP_OP_CONV || op.kind == FP_OP_DWPW) && op.res_mode == FP_RES_SHUFFLE2)
+                             ? 2 * (int64_t)Cout : Cout;
   const int64_t out_ext =
       (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (out_ch - 1) * op.out_cmul + 1;
   if (!span_ok(op.out_off, out_ext, arena_floats)) return FP_ERR_BOUNDS;
@@ -89,6 +90,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     // bias_off: optional [Cout4] PReLU slopes of the projection output
     if (op.bias_off >= 0 && !span_ok(op.bias_off, (op.Cout + 3) / 4 * 4, weight_floats)) return FP_ERR_BOUNDS;
     if (op.bias_off >= 0 && op.res_mode != FP_RES_NONE) return FP_ERR_UNSUPPORTED;
+    if (op.act2 != FP_ACT_NONE && op.act2 != FP_ACT_SILU) return FP_ERR_INVALID_ARG;
+  } else if (op.act2 != FP_ACT_NONE) {
+    return FP_ERR_INVALID_ARG;
   }
   if (op.kind == FP_OP_YSTEM || op.kind == FP_OP_YSTEM_U8) {
     if (op.Cin != (ext_in ? 3 : 4) || op.res_C <= 0 || op.res_C > 32 || op.Cout > 32) return FP_ERR_UNSUPPORTED;
@@ -111,7 +115,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   }
   if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW) && op.res_mode != FP_RES_NONE) {
     if (op.res_mode < FP_RES_NONE || op.res_mode > FP_RES_SHUFFLE2) return FP_ERR_INVALID_ARG;
-    if (op.res_mode == FP_RES_SHUFFLE2 && (op.kind != FP_OP_CONV || op.out_cmul != 1 || op.out_ld < 2 * op.Cout))
+    if (op.res_mode == FP_RES_SHUFFLE2 &&
+        ((op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW) || op.out_cmul != 1 || op.out_ld < 2 * op.Cout))
       return FP_ERR_INVALID_ARG;
     if (op.res_C <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
     int rh = OH, rw = OW;

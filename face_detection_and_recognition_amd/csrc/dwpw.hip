@@ -30,6 +30,7 @@ struct DwPwArgs {
   int in_ld, out_ld, res_ld;
   long in_ns;
   int Npad, OHW, has_res, has_slope;
+  int out_silu, shuffle;   // per-tile kernel only: SiLU on the 1x1 output; ShuffleV2 tail (out[2n] = res[n], out[2n+1] = y[n])
   long M;
   int ntiles;
 #ifdef FP_DWPW_STAMPS
@@ -220,6 +221,17 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
         const f32x4 os = *(const f32x4*)(p.oslope + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * os[e];
+      }
+      if (p.out_silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fp_silu(v[e]);
+      }
+      if (p.shuffle) {   // cat(res, y) + channel_shuffle(2) as two 16-byte pieces (y5/models/common.py:21-31,169-176)
+        const f32x4 rr = *(const f32x4*)(p.res + m * p.res_ld + n);
+        const f32x4 o0 = {rr[0], v[0], rr[1], v[1]}, o1 = {rr[2], v[2], rr[3], v[3]};
+        *(f32x4*)(p.out + m * p.out_ld + 2 * n) = o0;
+        *(f32x4*)(p.out + m * p.out_ld + 2 * n + 4) = o1;
+        continue;
       }
       if (p.has_res) v += *(const f32x4*)(p.res + m * p.res_ld + n);
       *(f32x4*)(p.out + m * p.out_ld + n) = v;
@@ -561,6 +573,7 @@ static size_t dwpw_persist_lds(int NB, int G) {
 // Persistent pipelined kernel over tiles of 32 2x2 patches, 2 resident workgroups per CU.  Cout = 128 at stride 2
 // (a 5x5 window + 4 accumulators per lane) spills and measured slower than the per-tile kernel: left to that one.
 bool fp_dwpw_persistent(const fp_op& op) {
+  if (op.act2 != FP_ACT_NONE || op.res_mode == FP_RES_SHUFFLE2) return false;   // the per-tile kernel owns those epilogues
   const int NB = (int)fp_round_up(op.Cout, 32) / 32;
   if (!(NB == 2 || (NB == 4 && op.stride == 1))) return false;
   if (op.OH % 2 || op.OW % 2 || (op.stride == 2 && (op.H % 2 || op.W % 2))) return false;
@@ -584,10 +597,12 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
   const long OHW = (long)op.OH * op.OW;
   if (op.out_cmul != 1 || op.out_ns != OHW * op.out_ld) return FP_ERR_UNSUPPORTED;
   if (op.OH != (op.H + 2 - 3) / op.stride + 1 || op.OW != (op.W + 2 - 3) / op.stride + 1) return FP_ERR_INVALID_ARG;
-  const bool has_res = op.res_mode != FP_RES_NONE;
-  if (has_res && (op.res_mode != FP_RES_ADD_AFTER_ACT || op.res_ns != OHW * op.res_ld || op.res_ld % 4 || op.res_off % 4 ||
-                  op.res_C < op.Cout))
+  const bool has_res = op.res_mode != FP_RES_NONE, shuffle = op.res_mode == FP_RES_SHUFFLE2;
+  if (has_res && ((op.res_mode != FP_RES_ADD_AFTER_ACT && !shuffle) || op.res_ns != OHW * op.res_ld || op.res_ld % 4 ||
+                  op.res_off % 4 || op.res_C < op.Cout))
     return FP_ERR_UNSUPPORTED;
+  if (shuffle && op.out_ld < 2 * op.Cout) return FP_ERR_INVALID_ARG;
+  if (op.act2 != FP_ACT_NONE && op.act2 != FP_ACT_SILU) return FP_ERR_UNSUPPORTED;
   DwPwArgs a;
   a.in = arena + op.in_off;
   a.out = arena + op.out_off;
@@ -600,7 +615,9 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
   a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.res_ld = op.res_ld; a.in_ns = op.in_ns;
   a.Npad = (int)fp_round_up(op.Cout, 32);
   a.OHW = (int)OHW;
-  a.has_res = has_res ? 1 : 0;
+  a.has_res = (has_res && !shuffle) ? 1 : 0;
+  a.shuffle = shuffle ? 1 : 0;
+  a.out_silu = op.act2 == FP_ACT_SILU ? 1 : 0;
   a.has_slope = op.act == FP_ACT_PRELU ? 1 : 0;
   a.M = (long)op.N * OHW;
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;

@@ -241,6 +241,8 @@ class ShuffleV2Block(_NoCompute):
                                      ConvParams(bf, bf, 3, stride, 1, groups=bf, bias=False), BNParams(bf, eps=1e-3),
                                      ConvParams(bf, bf, 1, 1, 0, bias=False), BNParams(bf, eps=1e-3), _Tag())
 
+    FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pairs (A/B parity tests)
+
     def emit(self, pb, x, out=None):
         """out: optional View (C = oup) the block writes into, e.g. a channel slice of a later Concat's buffer."""
         s = self.stride
@@ -250,38 +252,52 @@ class ShuffleV2Block(_NoCompute):
         ob, oc = out.buf, out.coff
         # cat + channel_shuffle(2) is the last conv's epilogue (FP_RES_SHUFFLE2): out[2n] = other half, out[2n+1] = conv
         b2 = self.branch2
+        fuse2 = ShuffleV2Block.FUSE and self.bf % 64 == 0 and self.bf <= 128     # dw3x3 + 1x1 of branch2 in one kernel
         if s == 1:
             first = View(x.buf, x.coff, self.bf)                                          # x1 passthrough
             x2 = View(x.buf, x.coff + self.bf, self.bf)
             b1out = None
         else:
             b1 = self.branch1
-            t = pb.new_buf(OH, OW, self.inp)
-            sc, bi = _bn_sb(b1[1])
-            pb.dwconv(x, npy(b1[0].weight), t.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
-            sc, bi = _bn_sb(b1[3])
             b1out = pb.new_buf(OH, OW, self.bf)
-            pb.conv(t.view(), npy(b1[2].weight), b1out.view(), scale=sc, bias=bi, act=L.ACT_SILU)
-            pb.free(t)
+            sc, bi = _bn_sb(b1[1])
+            sc2, bi2 = _bn_sb(b1[3])
+            if ShuffleV2Block.FUSE and self.inp % 64 == 0 and self.bf <= 128:
+                # branch1: dw3x3 s2 + BN -> 1x1 + BN + SiLU as one FP_OP_DWPW (the depthwise result stays in LDS)
+                pb.dwpw(x, npy(b1[0].weight), sc, bi, None, npy(b1[2].weight), sc2, bi2, b1out.view(), s,
+                        out_act=L.ACT_SILU)
+            else:
+                t = pb.new_buf(OH, OW, self.inp)
+                pb.dwconv(x, npy(b1[0].weight), t.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
+                pb.conv(t.view(), npy(b1[2].weight), b1out.view(), scale=sc2, bias=bi2, act=L.ACT_SILU)
+                pb.free(t)
             first = b1out.view()
             x2 = x
         t1 = pb.new_buf(x.H, x.W, self.bf)
         sc, bi = _bn_sb(b2[1])
         pb.conv(x2, npy(b2[0].weight), t1.view(), scale=sc, bias=bi, act=L.ACT_SILU)
-        t2 = pb.new_buf(OH, OW, self.bf)
         sc, bi = _bn_sb(b2[4])
-        pb.dwconv(t1.view(), npy(b2[3].weight), t2.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
-        pb.free(t1)
-        sc, bi = _bn_sb(b2[6])
-        if self.bf % 4 == 0:
-            pb.conv(t2.view(), npy(b2[5].weight), View(ob, oc, self.bf), scale=sc, bias=bi, act=L.ACT_SILU,
-                    res=first, res_mode=L.RES_SHUFFLE2)
-        else:   # odd widths: scalar interleaved writes
-            pb.copy(first, View(ob, oc, self.bf, cmul=2))
-            pb.conv(t2.view(), npy(b2[5].weight), View(ob, oc + 1, self.bf, cmul=2), scale=sc, bias=bi, act=L.ACT_SILU)
+        sc2, bi2 = _bn_sb(b2[6])
+        if fuse2:
+            # branch2 tail: dw3x3 + BN -> 1x1 + BN + SiLU -> cat + channel_shuffle in one kernel (FP_OP_DWPW with the
+            # FP_RES_SHUFFLE2 epilogue): the depthwise tensor never reaches HBM
+            pb.dwpw(t1.view(), npy(b2[3].weight), sc, bi, None, npy(b2[5].weight), sc2, bi2, View(ob, oc, self.bf), s,
+                    res=first, out_act=L.ACT_SILU, shuffle=True)
+            pb.free(t1)
+        else:
+            t2 = pb.new_buf(OH, OW, self.bf)
+            pb.dwconv(t1.view(), npy(b2[3].weight), t2.view(), stride=s, pad=(1, 1), scale=sc, bias=bi)
+            pb.free(t1)
+            if self.bf % 4 == 0:
+                pb.conv(t2.view(), npy(b2[5].weight), View(ob, oc, self.bf), scale=sc2, bias=bi2, act=L.ACT_SILU,
+                        res=first, res_mode=L.RES_SHUFFLE2)
+            else:   # odd widths: scalar interleaved writes
+                pb.copy(first, View(ob, oc, self.bf, cmul=2))
+                pb.conv(t2.view(), npy(b2[5].weight), View(ob, oc + 1, self.bf, cmul=2), scale=sc2, bias=bi2,
+                        act=L.ACT_SILU)
+            pb.free(t2)
         if b1out is not None:
             pb.free(b1out)
-        pb.free(t2)
         return out
 
 

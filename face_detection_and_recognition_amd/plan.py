@@ -275,14 +275,21 @@ class PlanBuilder:
         return out
 
     def dwpw(self, x, dw_w, dw_scale, dw_bias, dw_slope, pw_w, pw_scale, pw_bias, out, stride, res=None,
-             out_slope=None):
+             out_slope=None, out_act=L.ACT_NONE, shuffle=False):
         """Fused Depth_Wise tail (mobile_facenet.py:72-85): dw3x3 stride s (+BN affine, +PReLU) -> 1x1 (+BN affine)
         [+ res], or -- with out_slope -- a depthwise Conv_block followed by a 1x1 Conv_block (BN + PReLU on both:
         conv2_dw -> conv_23.conv, mobile_facenet.py:117-118,70).  x has G (multiple of 64) channels."""
         G = dw_w.shape[0]
         cout, cin = pw_w.shape[0], pw_w.shape[1]
-        assert cin == G == x.C and G % 64 == 0 and out.cmul == 1 and out.coff == 0 and out.buf.ld == out.C
+        assert cin == G == x.C and G % 64 == 0 and out.cmul == 1
+        # out_act = ACT_SILU: SiLU on the 1x1 output; shuffle: `out` is the dense view of the conv's own Cout channels
+        # inside a buffer that receives 2*Cout (out[2n] = res[n], out[2n+1] = y[n]: ShuffleV2Block's cat + shuffle)
+        if shuffle:
+            assert res is not None and res.C >= out.C and out.coff + 2 * out.C <= out.buf.ld
+        else:
+            assert out.coff == 0 and out.buf.ld == out.C or out_act != L.ACT_NONE
         op = self._base(L.OP_DWPW, x, out, out.H, out.W)
+        op.act2 = out_act
         op.Cout = out.C
         op.KH = op.KW = 3
         op.stride = stride
@@ -299,7 +306,7 @@ class PlanBuilder:
             op.bias_off = self.add_weight(pad_vec(out_slope, c4))
         if res is not None:
             assert res.cmul == 1
-            op.res_mode = L.RES_ADD_AFTER_ACT
+            op.res_mode = L.RES_SHUFFLE2 if shuffle else L.RES_ADD_AFTER_ACT
             op.res_ld, op.res_ns = res.buf.ld, res.buf.ns
             op.res_off = res.buf.off + res.coff
             op.res_C = min(res.C, out.C)

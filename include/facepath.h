@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 1
+#define FP_ABI_VERSION 2
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -103,6 +103,8 @@ typedef struct fp_op {
   int64_t in_ns, out_ns, res_ns;   /* per-image stride (floats) */
   int64_t in_off, out_off, res_off;
   int64_t w_off, scale_off, bias_off, slope_off;
+  int32_t act2;                    /* fused ops: activation of the SECOND conv's output (DWPW: FP_ACT_NONE / FP_ACT_SILU) */
+  int32_t reserved;                /* 0 */
 } fp_op;
 
 /*
@@ -117,6 +119,9 @@ typedef struct fp_op {
  *            act = FP_ACT_PRELU if the depthwise has a PReLU; res_mode = FP_RES_ADD_AFTER_ACT adds res after the 1x1.
  *            bias_off  -> optional [roundup(Cout,4)] PReLU slopes applied to the 1x1 output (a depthwise Conv_block
  *            followed by a 1x1 Conv_block, mobile_facenet.py:117-118,70); not combined with a residual.
+ *            act2 = FP_ACT_SILU applies SiLU to the 1x1 output; res_mode = FP_RES_SHUFFLE2 then writes the tail of a
+ *            ShuffleV2Block branch (y5/models/common.py:127-176: dw3x3 + BN -> 1x1 + BN + SiLU, cat with the other
+ *            half, channel_shuffle(2)) exactly as FP_OP_CONV does: out[2n] = res[n], out[2n+1] = y[n].
  *   BLAZEBLOCK : w_off -> [9][Cin] taps, scale_off -> [Cin] depthwise bias, slope_off -> packed 1x1, bias_off -> [Cout]
  *   YSTEM  : in = the 4-float-pixel image (Cin = in_ld = 4), H and W multiples of 4; OH x OW = H/2 x W/2 (stem_1 / stem_2a
  *            map), Cout = stem_2a's physical channels (<= 32); the res_* view receives maxpool2x2(stem_1):

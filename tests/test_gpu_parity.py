@@ -483,6 +483,32 @@ def test_yolo_block_vs_reference_golden(dev, tag):
         blk.fuse()
         got = _run_yolo_block(blk, g["conv_x"], dev)[:, :want.shape[1]]
         assert rel_err(got, g["conv_y_fused"]) < 1e-5
+    if tag.startswith("shuffle"):          # the unfused DWCONV + CONV form of the branches (default: FP_OP_DWPW)
+        Y.ShuffleV2Block.FUSE = False
+        try:
+            got = _run_yolo_block(blk, g[f"{tag}_x"], dev)[:, :want.shape[1]]
+        finally:
+            Y.ShuffleV2Block.FUSE = True
+        assert rel_err(got, want) < 1e-5, tag
+
+
+def test_yolo_shufflev2_fused_branches_at_stage_shapes(dev):
+    """Stage-3 shapes of yolov5n (128 -> 256 stride 2 with BOTH branches fused, then 256 -> 256 stride 1) on a ragged
+    map: FP_OP_DWPW with the SiLU / FP_RES_SHUFFLE2 epilogue against the oracle block."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    from oracle import yolo_ref
+    rng = np.random.default_rng(12)
+    for blk, cin, stride in ((Y.ShuffleV2Block(128, 256, 2), 128, 2), (Y.ShuffleV2Block(256, 256, 1), 256, 1)):
+        blk.load_state_dict(synth_state_dict(blk.state_dict(), 640 + stride))
+        x = rng.normal(0, 1, (3, cin, 22, 26)).astype(np.float32)
+        pb = PlanBuilder(3)
+        assert sum(1 for op in (blk.emit(pb, pb.new_buf(22, 26, cin).view()), pb)[1].ops if op.kind == L.OP_DWPW) == \
+            (2 if stride == 2 else 1)
+        got = _run_yolo_block(blk.to(dev), x, dev)
+        with torch.no_grad():
+            want = yolo_ref._shuffle_block({k: v.cpu() for k, v in blk.state_dict().items()}, "", torch.from_numpy(x),
+                                           stride).numpy()
+        assert rel_err(got[:, :want.shape[1]], want) < 1e-5
 
 
 @pytest.mark.parametrize("c,hw,fuse_bn", [(32, (72, 88), False), (24, (40, 136), True), (16, (64, 64), True)])

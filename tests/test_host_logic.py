@@ -26,13 +26,14 @@ def test_library_exports_every_declared_symbol(lib):
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in facepath.h but not exported: {missing}"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.fp_abi_version() == 1
+    assert lib.fp_abi_version() == L.ABI_VERSION == int(re.search(r"#define FP_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.fp_strerror(-2).decode().startswith("op touches")
 
 
 def test_struct_layout_matches_header():
-    # 22 int32 + 10 int64 = 168 bytes; fp_resize_item = 9 int32
-    assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8
+    # 22 int32 + 10 int64 + 2 int32 (act2, reserved) = 176 bytes; fp_resize_item = 9 int32; fp_ext = pointer + size_t
+    assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8 + 2 * 4
+    assert ctypes.sizeof(L.FpExt) == 16
     assert ctypes.sizeof(L.FpResizeItem) == 36
 
 
