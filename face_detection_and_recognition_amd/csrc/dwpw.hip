@@ -211,11 +211,26 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
     }
     __syncthreads();
     const int ncol0 = pass * PW * 32;
-    for (int f = tid; f < TM * F4_PER_ROW; f += 256) {
+    constexpr int NEP = TM * F4_PER_ROW / 256;   // float4s per lane and pass
+    f32x4 rr[NEP];
+    bool ok[NEP];
+#pragma unroll
+    for (int j = 0; j < NEP; ++j) {              // every residual load of the pass first: vmcnt counts loads and stores
+      const int f = tid + 256 * j;               // together, a load inside the store loop waits for the stores before it
       const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
       const long m = m0 + row;
       const int n = ncol0 + c4 * 4;
-      if (m >= p.M || n >= p.Cout) continue;
+      ok[j] = m < p.M && n < p.Cout;
+      rr[j] = z;
+      if (ok[j] && (p.has_res || p.shuffle)) rr[j] = *(const f32x4*)(p.res + m * p.res_ld + n);
+    }
+#pragma unroll
+    for (int j = 0; j < NEP; ++j) {
+      const int f = tid + 256 * j;
+      const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+      const long m = m0 + row;
+      const int n = ncol0 + c4 * 4;
+      if (!ok[j]) continue;
       f32x4 v = *(const f32x4*)&smem[row * LDO + c4 * 4];
       if (p.oslope) {
         const f32x4 os = *(const f32x4*)(p.oslope + n);
@@ -227,13 +242,12 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
         for (int e = 0; e < 4; ++e) v[e] = fp_silu(v[e]);
       }
       if (p.shuffle) {   // cat(res, y) + channel_shuffle(2) as two 16-byte pieces (y5/models/common.py:21-31,169-176)
-        const f32x4 rr = *(const f32x4*)(p.res + m * p.res_ld + n);
-        const f32x4 o0 = {rr[0], v[0], rr[1], v[1]}, o1 = {rr[2], v[2], rr[3], v[3]};
+        const f32x4 o0 = {rr[j][0], v[0], rr[j][1], v[1]}, o1 = {rr[j][2], v[2], rr[j][3], v[3]};
         *(f32x4*)(p.out + m * p.out_ld + 2 * n) = o0;
         *(f32x4*)(p.out + m * p.out_ld + 2 * n + 4) = o1;
         continue;
       }
-      if (p.has_res) v += *(const f32x4*)(p.res + m * p.res_ld + n);
+      if (p.has_res) v += rr[j];
       *(f32x4*)(p.out + m * p.out_ld + n) = v;
     }
   }
