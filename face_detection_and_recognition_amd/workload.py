@@ -115,10 +115,16 @@ def build_yolo_detector(device, calib_frames, name="yolov5s", cand_per_frame=80,
     in_w, in_h = input_size
 
     def obj_logits():
+        """(B, rows) raw objectness logits in z's row order (level, anchor, y, x), read from the raw head tensors (the
+        decoded z holds sigmoid(logit), which saturates at +-16 in fp32)."""
         m._plans.clear()
-        z = m.run_plan(preprocess_batch(m, calib_frames, input_size))
-        obj = z[..., 4].clamp(1e-7, 1 - 1e-7)
-        return torch.log(obj / (1 - obj))                      # (B, rows), rows ordered (level, anchor, y, x)
+        plan = preprocess_batch(m, calib_frames, input_size)
+        m.run_plan(plan)
+        parts = []
+        for h in plan.heads:                                   # (B, ny, nx, na * no)
+            b, ny, nx, _ = h.shape
+            parts.append(h.view(b, ny, nx, det.na, det.no)[..., 4].permute(0, 3, 1, 2).reshape(b, -1))
+        return torch.cat(parts, 1).clone()
 
     # random weights leave the objectness logit almost constant over the image (std ~0.01) and offset per (level,
     # anchor) by the random bias: normalise every (level, anchor) group to the same mean and a spread of ~obj_spread so
