@@ -9,6 +9,7 @@ tag=$1; shift
 root=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
+rm -rf "$root/gpurun_out/${tag}_stats" "$root/gpurun_out/${tag}_fetch" "$root/gpurun_out/${tag}_write"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/${tag}_stats" -- python3 "$root/$1" "${@:2}" > "$root/gpurun_out/${tag}_stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_fetch" -- python3 "$root/$1" "${@:2}" > "$root/gpurun_out/${tag}_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_write" -- python3 "$root/$1" "${@:2}" > "$root/gpurun_out/${tag}_write.log" 2>&1
