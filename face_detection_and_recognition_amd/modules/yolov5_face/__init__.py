@@ -26,6 +26,7 @@ def preprocess_batch(net, frames_u8, input_size):
     run: when the network's StemBlock can read u8 frames itself (FP_OP_YSTEM_U8) the letterbox happens inside its
     staging and no fp32 canvas exists; otherwise fp_resize_normalize fills the plan's NHWC input."""
     in_w, in_h = tuple(map(check_img_size, input_size))
+    frames_u8 = frames_u8.contiguous()
     B, fh, fw, _ = frames_u8.shape
     if net.letterbox_fusable(in_h, in_w) and fw >= 3 and fh <= 65535 and in_h + in_w <= 2048:
         plan = net.plan_for(B, in_h, in_w, frame_hw=(fh, fw))
