@@ -126,3 +126,55 @@ def test_yolo_plans_validate_and_keys():
     m2 = Model("yolov5s")
     m2.load_state_dict(m.state_dict())
     assert list(m2.state_dict()) == list(m.state_dict())
+
+
+def test_plan_cache_is_lru_bounded_and_shares_weights():
+    """the per-network plan cache must not pin one arena per batch size ever seen, and all plans of a
+    network share one copy of the packed weights."""
+    from face_detection_and_recognition_amd.plan import PlanCache
+    cache = PlanCache(max_plans=3)
+    built = []
+
+    def make(key):
+        def build(c):
+            built.append(key)
+            return ("plan", key)
+        return build
+    for k in (1, 2, 3):
+        assert cache.get(k, make(k)) == ("plan", k)
+    assert cache.get(1, make(1)) == ("plan", 1) and built == [1, 2, 3]          # hit: nothing rebuilt, 1 is now newest
+    cache.get(4, make(4))                                                       # evicts the least recently used: 2
+    assert len(cache) == 3 and 2 not in cache and 1 in cache and 3 in cache and 4 in cache
+    cache.get(2, make(2))
+    assert built == [1, 2, 3, 4, 2] and 3 not in cache
+    w = np.arange(8, dtype=np.float32)
+    d0 = cache.device_weights(w, torch.device("cpu"))
+    assert cache.device_weights(w.copy(), torch.device("cpu")) is d0              # same content: one device copy
+    assert cache.device_weights(w + 1, torch.device("cpu")) is not d0
+    cache.clear()
+    assert len(cache) == 0 and cache.device_weights(w, torch.device("cpu")) is not d0
+
+
+def test_fused_letterbox_plans_validate_on_host(lib):
+    """The plans whose first op reads u8 frames (FP_OP_STEM_U8 / FP_OP_YSTEM_U8) pass the C validator; the ops that
+    need external buffers are rejected by plain fp_plan_run-style validation of their shapes only when malformed."""
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model
+    for net, kind in ((BlazeFace(True), L.OP_STEM_U8), (BlazeFace(False), L.OP_STEM_U8)):
+        pb = net._emit(3, frame_hw=(576, 1024))[0]
+        assert pb.ops[0].kind == kind and pb.ops[0].res_H == 576 and pb.ops[0].res_W == 1024
+        assert validate_on_host(pb) == 0
+    for name in ("yolov5n", "yolov5s", "yolov5n-0.5"):
+        m = Model(name)
+        assert m.letterbox_fusable(640, 640)
+        pb = m._emit(2, 640, 640, frame_hw=(576, 1024))[0]
+        assert pb.ops[0].kind == L.OP_YSTEM_U8 and validate_on_host(pb) == 0
+        assert sum(1 for op in pb.ops if op.kind == L.OP_COPY) == 0                # Concat is addressing
+        bad = m._emit(2, 640, 640, frame_hw=(576, 1024))[0]
+        bad.ops[0].res_C = 40                                                      # stem_1 wider than the kernel handles
+        assert validate_on_host(bad) != 0
+    # tap-table entry point: argument validation happens before any launch
+    assert lib.fp_letterbox_tables(576, 1024, 640, 640, 0, 0, 1024, 576, 0, 140, 640, 360, 125, 1, None, None) != 0
+    buf = (ctypes.c_int32 * 8)()
+    assert lib.fp_letterbox_tables(576, 1024, 640, 640, 0, 0, 2048, 576, 0, 140, 640, 360, 125, 1, buf, None) != 0
+    assert lib.fp_letterbox_tables(576, 1024, 640, 640, 0, 0, 1024, 576, 0, 140, 640, 700, 125, 1, buf, None) != 0
+    assert lib.fp_letterbox_tables(70000, 1024, 640, 640, 0, 0, 1024, 70000, 0, 0, 640, 640, 125, 1, buf, None) != 0
