@@ -488,7 +488,7 @@ class Model(nn.Module):
                     if any(w % 4 for w in widths):
                         del place[m.i]              # unaligned width: fall back to a copy
                     else:
-                        oh, ow = self._out_hw(m, ins[0])
+                        oh, ow = self._out_hw(m, ins[0] if ins[0] is not None else pb.new_shape(H, W))
                         cat_bufs[cat_i] = pb.new_buf(oh, ow, sum(widths))
                         cat_bufs[cat_i].widths = widths
                 if m.i in place:

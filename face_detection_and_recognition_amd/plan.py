@@ -162,6 +162,11 @@ class PlanBuilder:
         self.peak = max(self.peak, self.arena.top)
         return off, size
 
+    @staticmethod
+    def new_shape(H, W):
+        """A shape-only stand-in for an input that is not an arena buffer (u8 frames read by a *_U8 op)."""
+        return Buf(H, W, 0, 0, 0)
+
     def free(self, buf):
         self.arena.release(buf.off, buf.size)
 
