@@ -163,7 +163,6 @@ def run_pipeline(args):
     batches = [W.make_frames(B_FRAMES, dev, seed=1234 + 97 * rank + b) for b in range(N_BATCHES)]
     det = W.build_detector(dev, W.make_frames(64, dev, seed=999), box_px=args.box_px)   # same calibration on every rank
     emb = W.build_embedder(dev)
-    emb._plans.max_plans = 8                   # a few 64-row buckets of face counts may alternate between batches
     ref = W.make_reference(N_REF, dev)
     pipe = FacePipeline(det, emb, ref, tau=0.3)
     gather_block = n_dev = None
@@ -202,8 +201,8 @@ def run_pipeline(args):
     # HIP events around an op cost a little, so: one un-timed probe pass over the batches with events on every op
     # finds the dominant kernel family; the timed steps then carry events only on that family's launches.
     det_plan = det.net.last_plan
-    emb_plans = list(emb._plans._plans.values())
-    plans = [det_plan] + emb_plans
+    emb_plan = pipe.emb_plan                   # one plan (arena capacity >= every step's face count), run on n_pad crops
+    plans = [det_plan, emb_plan]
     fam_ms = {}
     for k in range(N_BATCHES):
         probe = [p.new_timer() for p in plans]
@@ -250,16 +249,13 @@ def run_pipeline(args):
         ms_tot, launches, bytes_tot, pipe_bytes = 0.0, 0, 0.0, 0.0
         for k in range(args.steps):
             n_k = faces_per_step[k]
-            n_pad = (n_k + pipe.bucket - 1) // pipe.bucket * pipe.bucket
             for p, t, m in zip(plans, timers[k], masks):
                 ms = (ctypes.c_float * p.n_ops)()
                 p.accumulate(t, ms)
                 p.destroy_timer(t)
-                ran = p is det_plan or p.ops[0].N == n_pad
-                if not ran:
-                    continue
-                # Mobile-FaceNet runs on a batch padded to a multiple of 64 crops: algorithmic bytes count the REAL faces
-                real = 1.0 if p is det_plan else n_k / float(n_pad)
+                # Mobile-FaceNet's plan is emitted for its arena capacity and run on the step's crops (padded to a
+                # multiple of 8): algorithmic bytes count the REAL faces of the step
+                real = 1.0 if p is det_plan else n_k / float(p.N)
                 for i in range(p.n_ops):
                     pipe_bytes += p.algorithmic_bytes(i) * real
                     if m[i]:

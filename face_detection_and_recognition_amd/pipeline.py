@@ -30,7 +30,7 @@ class FacePipeline:
     """detector: a BlazeFaceModel or YOLOV5FaceModel (HIP); embedder: a HIP MobileFaceNet;
     reference: (Nr, E) CUDA tensor of reference embeddings for the cosine filter (or None)."""
 
-    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=64):
+    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=8):
         self.det = detector
         self.emb = embedder
         self.tau = float(tau)
@@ -71,13 +71,20 @@ class FacePipeline:
         return items, info, nf
 
     def embed(self, frames, items, n_faces):
-        """Crop + resize + normalise into the embedder's input, run Mobile-FaceNet.  -> (n_faces, E)."""
+        """Crop + resize + normalise into the embedder's input, run Mobile-FaceNet.  -> (n_faces, E), a view into the
+        embedder plan's arena.  ONE plan (arena sized for the largest batch seen, in steps of 256 crops) serves every
+        face count: it runs on the first n_pad = n_faces rounded up to `bucket` images (8 keeps the 14x14 layers'
+        row count a multiple of the 32-row MFMA tiles the streaming 1x1 kernels need), so at most bucket - 1 crops of
+        work are padding and a varying face count neither builds new plans nor pins new arenas."""
         if n_faces == 0:
             return torch.zeros((0, self.emb.embedding_size), device=self.dev)
         n_pad = (n_faces + self.bucket - 1) // self.bucket * self.bucket
-        plan = self.emb.plan_for(n_pad)
+        cap = max(getattr(self, "_emb_cap", 0), (n_pad + 255) // 256 * 256)
+        self._emb_cap = cap
+        plan = self.emb.plan_for(cap)
+        self.emb_plan, self.emb_n_pad = plan, n_pad
         crops_to_input(frames, items, n_faces, plan.input, self.lut)
-        plan.run()
+        plan.run(n=n_pad)
         return plan.out[:n_faces]
 
     def filter(self, emb):

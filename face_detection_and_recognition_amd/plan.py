@@ -491,6 +491,8 @@ class CompiledPlan:
         import torch
         ops, weights, arena_floats = builder.finish()
         self.n_ops = len(ops)
+        self.N = builder.N            # batch capacity: the arena holds N images; run(n=...) may process fewer
+        self.n_run = builder.N
         self.alg_bytes = list(builder.alg_bytes)
         assert len(self.alg_bytes) == self.n_ops
         self.ops = (L.FpOp * max(self.n_ops, 1))(*ops)
@@ -518,7 +520,21 @@ class CompiledPlan:
         self._ext = (L.FpExt * max(len(tensors), 1))(*[L.FpExt(t.data_ptr(), t.numel() * t.element_size())
                                                       for t in tensors])
 
-    def run(self):
+    def set_batch(self, n):
+        """Process only the first n <= N images on the following runs.  Every per-image stride of an op is independent
+        of the batch size, so this only rewrites the ops' N field; kernel selection (persistent / streaming / per-tile)
+        follows the actual n at launch time."""
+        n = int(n)
+        if not 0 < n <= self.N:
+            raise ValueError(f"batch {n} outside the plan's capacity 1..{self.N}")
+        if n != self.n_run:
+            for i in range(self.n_ops):
+                self.ops[i].N = n
+            self.n_run = n
+
+    def run(self, n=None):
+        if n is not None:
+            self.set_batch(n)
         if self._timing is not None:
             return self.run_timed(*self._timing)
         rc = self.lib.fp_plan_run_ext(self.ops, self.n_ops, L.ptr(self.weights), self.weights.numel(),

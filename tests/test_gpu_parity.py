@@ -376,6 +376,30 @@ def test_mobilefacenet_forward_vs_reference_golden(dev):
     np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)
 
 
+def test_plan_runs_on_a_prefix_of_its_capacity(dev):
+    """CompiledPlan.run(n): a plan emitted for a capacity of 40 crops processes the first 16 / 24 of them and gives
+    exactly what a plan emitted for that batch size gives (FacePipeline keeps ONE embedder plan for every face count)."""
+    net = MobileFaceNet(512)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 300))
+    net = net.to(dev)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.uniform(-1, 1, (40, 112, 112, 3)).astype(np.float32)).to(dev)
+    big = net.plan_for(40)
+    big.input.zero_()
+    big.input[..., :3].copy_(x)
+    for n in (16, 24, 40):
+        big.run(n=n)
+        got = big.out[:n].clone()
+        small = net.plan_for(n)
+        small.input.zero_()
+        small.input[..., :3].copy_(x[:n])
+        small.run()
+        torch.cuda.synchronize()
+        assert torch.equal(got, small.out[:n])
+    with pytest.raises(ValueError):
+        big.run(n=41)
+
+
 def test_resize_normalize_vs_oracle(dev, lib):
     rng = np.random.default_rng(3)
     frames = rng.integers(0, 256, (3, 72, 128, 3), dtype=np.uint8)
