@@ -591,7 +591,10 @@ bool fp_dwpw_persistent(const fp_op& op) {
   const int NB = (int)fp_round_up(op.Cout, 32) / 32;
   if (!(NB == 2 || (NB == 4 && op.stride == 1))) return false;
   if (op.OH % 2 || op.OW % 2 || (op.stride == 2 && (op.H % 2 || op.W % 2))) return false;
-  if ((long)op.N * op.OH * op.OW < 1024L * TM) return false;
+#ifndef FP_DWPW_PERSIST_MIN_TILES
+#define FP_DWPW_PERSIST_MIN_TILES 512L   // one tile per persistent workgroup: 108 vs 119 us on the 14x14 blocks at 528 crops
+#endif
+  if ((long)op.N * op.OH * op.OW < FP_DWPW_PERSIST_MIN_TILES * TM) return false;
   return dwpw_persist_lds(NB, op.Cin) <= 80 * 1024;
 }
 
