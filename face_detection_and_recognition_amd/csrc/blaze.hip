@@ -243,6 +243,11 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
     pos = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
   }
 
+  // Window loads use 32-bit BYTE offsets from the (wave-uniform, SGPR) tensor base: one address register and one
+  // v_add_u32 per load instead of a 64-bit multiply-add each (the launcher checks the tensor is < 4 GiB).  The fused
+  // kernel is VALU-issue bound (~800 VALU instructions per 12 MFMAs), and address arithmetic was a
+  // quarter of them.
+  const char* inb = (const char*)p.in;
   f32x4 x[3][WIN];
   auto issue_loads = [&](long tile) {
     long m = tile * TM + r;
@@ -251,19 +256,26 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
     const unsigned img = mm / (unsigned)p.OHW;
     const unsigned rem = mm - img * (unsigned)p.OHW;
     const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
-    const float* ib = p.in + (long)img * p.in_ns + c;
+    const unsigned ib = (img * (unsigned)p.in_ns + (unsigned)c) * 4u;
+    const unsigned row_b = (unsigned)(p.W * p.in_ld) * 4u, px_b = (unsigned)p.in_ld * 4u;
     const int iy0 = S == 1 ? oy - 1 : 2 * oy, ix0 = S == 1 ? ox - 1 : 2 * ox;
+    unsigned colo[WIN];
+    unsigned vx = 0;
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+      const int ix = ix0 + j;
+      colo[j] = (unsigned)min(max(ix, 0), p.W - 1) * px_b;
+      if ((unsigned)ix < (unsigned)p.W) vx |= 1u << j;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = iy0 + ky;
       const bool vy = (unsigned)iy < (unsigned)p.H;
-      const float* rowp = ib + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+      const unsigned rowo = ib + (unsigned)min(max(iy, 0), p.H - 1) * row_b;
 #pragma unroll
       for (int j = 0; j < WIN; ++j) {
-        const int ix = ix0 + j;
-        const bool v = vy && ((unsigned)ix < (unsigned)p.W);
-        const f32x4 t = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
-        x[ky][j] = v ? t : z;
+        const f32x4 t = *(const f32x4*)(inb + (rowo + colo[j]));
+        x[ky][j] = (vy && ((vx >> j) & 1u)) ? t : z;
       }
     }
   };
@@ -375,7 +387,8 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
   a.M = (long)op.N * a.OHW;
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;
   a.ntiles = fp_ceil_div(a.M, TM);
-  if (a.Kpad <= 32 && a.Npad == 32 && a.ntiles >= 2048) {
+  if (a.Kpad <= 32 && a.Npad == 32 && a.ntiles >= 2048 &&
+      (unsigned long long)op.N * (unsigned long long)op.in_ns * 4ull < (1ull << 32)) {   // 32-bit byte offsets
     // persistent kernel: 3 (stride 1) / 2 (stride 2) resident workgroups per CU, each striding over the tiles
     const size_t plds = 4 * ((size_t)TM * (a.Kpad + 4) + (size_t)TM * (op.Cin + 4) + (size_t)TM * op.Cout +
                              (size_t)a.Kpad * 32 + (size_t)10 * op.Cin);
