@@ -202,16 +202,36 @@ class C3(_NoCompute):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
+    MERGE = True   # class-wide switch: False emits cv1 and cv2 as separate convs (A/B parity tests)
+
     def emit(self, pb, x, out=None):
         assert self.c_ % 4 == 0, "C3 hidden width must be a multiple of 4 for the in-place concat"
-        cat = pb.new_buf(x.H, x.W, 2 * self.c_)
-        t = self.cv1.emit(pb, x)
-        for i, b in enumerate(self.m):
-            last = i == len(self.m) - 1
-            y = b.emit(pb, t, out=cat.view(0, self.c_) if last else None)
-            pb.free(t.buf)
-            t = y
-        self.cv2.emit(pb, x, out=cat.view(self.c_, self.c_))
+        c_ = self.c_
+        cat = pb.new_buf(x.H, x.W, 2 * c_)
+        a, b = self.cv1, self.cv2
+        if C3.MERGE and (a.bn is None) == (b.bn is None) and a.act and b.act:
+            # cv1 and cv2 are two 1x1 convs on the same input whose outputs end up side by side in the concat: ONE conv
+            # with the weights stacked writes whole concat rows (x is read once; a conv that writes only one half of
+            # every row ran at half the store rate: 489 vs 232 us for 24 -> 24 at 160x160, profiles/r02_yolo).  The
+            # bottleneck chain then updates the first half in place (residual and output are the same view).
+            w = np.concatenate([npy(a.conv.weight), npy(b.conv.weight)], 0)
+            if a.bn is None:
+                kw = dict(bias=np.concatenate([npy(a.conv.bias), npy(b.conv.bias)]))
+            else:
+                (s1, b1), (s2, b2) = _bn_sb(a.bn), _bn_sb(b.bn)
+                kw = dict(scale=np.concatenate([s1, s2]), bias=np.concatenate([b1, b2]))
+            pb.conv(x, w, cat.view(0, 2 * c_), act=L.ACT_SILU, n_convs=2, **kw)
+            t = cat.view(0, c_)
+            for blk in self.m:
+                blk.emit(pb, t, out=t)
+        else:
+            t = a.emit(pb, x)
+            for i, blk in enumerate(self.m):
+                last = i == len(self.m) - 1
+                y = blk.emit(pb, t, out=cat.view(0, c_) if last else None)
+                pb.free(t.buf)
+                t = y
+            b.emit(pb, x, out=cat.view(c_, c_))
         out = self.cv3.emit(pb, cat.view(), out=out)
         pb.free(cat)
         return out

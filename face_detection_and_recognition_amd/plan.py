@@ -203,7 +203,7 @@ class PlanBuilder:
         return op
 
     def conv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None,
-             act=L.ACT_NONE, res=None, res_mode=L.RES_NONE):
+             act=L.ACT_NONE, res=None, res_mode=L.RES_NONE, n_convs=1):
         """Dense conv (OIHW weight); out is a View whose C >= Cout (extra channels get zeros)."""
         cout, cin, kh, kw = w.shape
         assert cin <= x.C, (cin, x.C)
@@ -230,7 +230,9 @@ class PlanBuilder:
             op.res_C = min(res.C, out.C)
             op.res_H, op.res_W = res.H, res.W
         self.ops.append(op)
-        self.alg_bytes.append(4 * self.N * (x.H * x.W * cin + OH * OW * cout))
+        # n_convs > 1: several reference convs on the same input merged into one op (their outputs concatenated): the
+        # op-granular model counts the input once per conv
+        self.alg_bytes.append(4 * self.N * (n_convs * x.H * x.W * cin + OH * OW * cout))
         return out
 
     def dwconv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):

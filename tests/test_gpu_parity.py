@@ -507,6 +507,13 @@ def test_yolo_block_vs_reference_golden(dev, tag):
         blk.fuse()
         got = _run_yolo_block(blk, g["conv_x"], dev)[:, :want.shape[1]]
         assert rel_err(got, g["conv_y_fused"]) < 1e-5
+    if tag.startswith("c3"):               # cv1 / cv2 as separate convs (default: one conv writing whole concat rows)
+        Y.C3.MERGE = False
+        try:
+            got = _run_yolo_block(blk, g[f"{tag}_x"], dev)[:, :want.shape[1]]
+        finally:
+            Y.C3.MERGE = True
+        assert rel_err(got, want) < 1e-5, tag
     if tag.startswith("shuffle"):          # the unfused DWCONV + CONV form of the branches (default: FP_OP_DWPW)
         Y.ShuffleV2Block.FUSE = False
         try:
