@@ -336,8 +336,14 @@ class SPP(_NoCompute):
         cat = pb.new_buf(x.H, x.W, self.c_ * (len(self.k) + 1))
         first = cat.view(0, self.c_)
         self.cv1.emit(pb, x, out=first)
+        prev, prev_k = first, 1
         for i, k in enumerate(self.k):
-            pb.maxpool(first, cat.view(self.c_ * (i + 1), self.c_), k, 1, k // 2)
+            dst = cat.view(self.c_ * (i + 1), self.c_)
+            if k - prev_k == 2:     # stride-1 max pools cascade exactly: pool_k = pool_3(pool_{k-2}) (max is associative)
+                pb.maxpool(prev, dst, 3, 1, 1)
+            else:
+                pb.maxpool(first, dst, k, 1, k // 2)
+            prev, prev_k = dst, k
         y = self.cv2.emit(pb, cat.view(), out=out)
         pb.free(cat)
         return y
