@@ -158,7 +158,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
         return buf;
       }
       if (fp_conv3_eligible(*op)) {
-        snprintf(buf, sizeof(buf), "conv3_kernel<%d, %d>", fp_conv3_nb(*op), op->stride);
+        snprintf(buf, sizeof(buf), "conv3_kernel<%d, %d, %s>", fp_conv3_nb(*op), op->stride, fp_conv3_t16(*op) ? "true" : "false");
         return buf;
       }
       int nb, vec, pwd;

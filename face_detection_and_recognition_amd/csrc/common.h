@@ -61,5 +61,6 @@ int fp_ystem_nb2(const fp_op& op);
 int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s);
 bool fp_conv3_eligible(const fp_op& op);    // dense 3x3 pad-1 convs that take the LDS-image kernel (conv3.hip)
 int fp_conv3_nb(const fp_op& op);
+bool fp_conv3_t16(const fp_op& op);        // conv3 with 16-column n tiles (16x16x4 MFMA)
 int fp_launch_conv3(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd);  // conv_igemm template arguments for an op

@@ -12,7 +12,12 @@
 //               FP_OP_CONV (k = tap*Cin + c) are used as they are: chunk (tap, slab) is a contiguous run of k-quads
 //   pipeline  = the next slab's pixels and the next (tap, slab) weight chunk are loaded into registers while the
 //               current chunk's MFMAs run; weights are double-buffered in LDS: one barrier per tap
-//   MFMA      = v_mfma_f32_32x32x2_f32, wave w owns output rows 2w, 2w+1 of the tile (32 pixels), NB n tiles of 32
+//   MFMA      = v_mfma_f32_32x32x2_f32, wave w owns output rows 2w, 2w+1 of the tile (32 pixels), NB n tiles of 32;
+//               T16 variant: v_mfma_f32_16x16x4_f32 with NB n tiles of 16 columns, for widths whose padding to 32
+//               would waste a quarter of the MFMA work (YOLOv5s' 48 -> 48 bottlenecks: 3 tiles of 16 instead of 64
+//               columns).  Lane (r16, g) feeds A = pixel r16 of one tile row, k = 16*jj + 4*g + e -- one float4 of the
+//               LDS pixel per 4 MFMAs -- and B = k-quad 4*jj + g of the packed weights, which is the FP_OP_CONV layout
+//               as it is (the K permutation inside a 16-channel group is the same on both operands)
 //   epilogue  = acc*scale+bias through LDS, SiLU / none, optional residual added after the activation (Bottleneck
 //               shortcut), 16-byte stores into an arbitrary NHWC view (concat slices)
 // Sums run in a different k order than conv_igemm_kernel (slab-major instead of tap-major): fp32 reassociation only.
@@ -47,17 +52,19 @@ struct Geo {
   }
 };
 
-template <int NB, int S>
+template <int NB, int S, bool T16>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
   using G = Geo<S>;
-  constexpr int BN = NB * 32, CK = G::CK, P = G::P;
+  constexpr int BN = NB * (T16 ? 16 : 32), CK = G::CK, P = G::P;
   constexpr int LDO = BN + 4;
+  constexpr int NWS = (CK / 4 * BN + 255) / 256;   // weight-chunk float4 slots per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Img = smem;                               // [NPIX][P]
   float* Bs = Img + G::NPIX * P;                   // [2][CK/4 + 1][BN][4]   (+1 zero quad for odd quad counts)
   constexpr int BQ = CK / 4 + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
+  const int r16 = lane & 15, g = lane >> 4;        // T16 fragment coordinates
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
   const int tile = blockIdx.x, n0 = blockIdx.y * BN;
@@ -93,15 +100,14 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
       if (px < G::IH * G::IW) *(f32x4*)&Img[G::lds_px(r, c) * P + q * 4] = ((imask >> j) & 1u) ? ireg[j] : z4;
     }
   };
-  f32x4 breg[NB];
+  f32x4 breg[NWS];
   unsigned bmask = 0;
   auto load_w = [&](int kq0, int nq) {             // nq k-quads starting at global quad kq0, columns n0 .. n0 + BN
     bmask = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < NWS; ++j) {
       const int idx = tid + 256 * j;
       const int q = idx / BN, col = idx - q * BN;
-      if (CK / 4 * BN <= 256 * j) continue;        // (compile-time) more slots than the chunk has float4s
       breg[j] = *(const f32x4*)(p.w + ((long)(kq0 + min(q, nq - 1)) * p.Npad + min(n0 + col, p.Npad - 1)) * 4);
       if (q < nq && n0 + col < p.Npad) bmask |= 1u << j;
     }
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
   auto store_w = [&](int buf) {
     float* b = Bs + buf * BQ * BN * 4;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < NWS; ++j) {
       const int idx = tid + 256 * j;
       if (idx < CK / 4 * BN) *(f32x4*)&b[idx * 4] = ((bmask >> j) & 1u) ? breg[j] : z4;
     }
@@ -120,14 +126,19 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
   // pad floats of every LDS pixel (read as A values beyond a short slab): zero once
   for (int i = tid; i < G::NPIX; i += 256) *(f32x4*)&Img[i * P + CK] = z4;
 
-  f32x16 acc[NB];
+  f32x16 acc[T16 ? 1 : NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+  for (int nb = 0; nb < (T16 ? 1 : NB); ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
   f32x16 acc1;                                     // NB = 1: second partial sum (odd k-steps)
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+  f32x4 acc16[2][T16 ? NB : 1];                    // T16: [tile row 2w + m][n tile of 16]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nb = 0; nb < (T16 ? NB : 1); ++nb) acc16[m][nb] = z4;
 
   // this lane's output pixel inside the tile: rows 2w, 2w+1; lr -> (y, x)
   const int py = 2 * wave + (lr >> 4), pxx = lr & 15;
@@ -149,8 +160,31 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
         if (sn < nslab) load_w((tn * p.Cin + sn * CK) >> 2, min(CK, p.Cin - sn * CK) >> 2);
       }
       const int ky = t / 3, kx = t - ky * 3;
-      const float* arow = Img + G::lds_px(py * S + ky, pxx * S + kx) * P + 4 * h;
       const float* bb = Bs + buf * BQ * BN * 4;
+      if constexpr (T16) {
+        const float* arow0 = Img + G::lds_px((2 * wave) * S + ky, r16 * S + kx) * P + 4 * g;
+        const float* arow1 = Img + G::lds_px((2 * wave + 1) * S + ky, r16 * S + kx) * P + 4 * g;
+#pragma unroll
+        for (int jj = 0; jj < CK / 16; ++jj) {
+          if (jj * 4 < nq) {
+            const f32x4 a0 = *(const f32x4*)(arow0 + jj * 16), a1 = *(const f32x4*)(arow1 + jj * 16);
+            f32x4 b[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)&bb[((jj * 4 + g) * BN + nb * 16 + r16) * 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) {
+                acc16[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b[nb][e], acc16[0][nb], 0, 0, 0);
+                FP_MFMA_ORDER();
+                acc16[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b[nb][e], acc16[1][nb], 0, 0, 0);
+                FP_MFMA_ORDER();
+              }
+            }
+          }
+        }
+      } else {
+      const float* arow = Img + G::lds_px(py * S + ky, pxx * S + kx) * P + 4 * h;
 #pragma unroll
       for (int kq = 0; kq < CK / 8; ++kq) {
         if (kq * 2 < nq) {
@@ -176,10 +210,11 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
           }
         }
       }
+      }
       buf ^= 1;
     }
   }
-  if (NB == 1) {
+  if (NB == 1 && !T16) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] += acc1[r];
   }
@@ -189,27 +224,37 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
   float sc[NB], bi[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = n0 + nb * 32 + lr;
+    const int n = T16 ? n0 + nb * 16 + r16 : n0 + nb * 32 + lr;
     const int nn = n < p.Cout ? n : 0;
     sc[nb] = p.scale ? p.scale[nn] : 1.f;
     bi[nb] = p.bias ? p.bias[nn] : 0.f;
   }
   float* Ot = smem;
-  constexpr int F4_PER_ROW = NB * 8;
-  constexpr int NIT = 64 * F4_PER_ROW / 256;       // 2 * NB float4 per thread and pass
+  constexpr int F4_PER_ROW = BN / 4;
+  constexpr int NIT = 64 * F4_PER_ROW / 256;       // BN / 16 float4 per thread and pass
   const bool silu = p.act == FP_ACT_SILU;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (pass) __syncthreads();
     if ((wave >> 1) == pass) {
       const int wrow = (wave & 1) * 32;
+      if constexpr (T16) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = wrow + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          Ot[row * LDO + nb * 32 + lr] = acc[nb][reg] * sc[nb] + bi[nb];
-        }
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)      // 16x16x4 C/D: column = lane & 15, row = 4 * (lane >> 4) + reg
+              Ot[(wrow + m * 16 + 4 * g + reg) * LDO + nb * 16 + r16] = acc16[m][nb][reg] * sc[nb] + bi[nb];
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = wrow + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            Ot[row * LDO + nb * 32 + lr] = acc[nb][reg] * sc[nb] + bi[nb];
+          }
+      }
     }
     __syncthreads();
     f32x4 rr[NIT];
@@ -242,11 +287,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args p) {
   }
 }
 
-template <int NB, int S>
+template <int NB, int S, bool T16>
 size_t conv3_lds_bytes() {
   using G = Geo<S>;
-  const size_t main_b = 4 * ((size_t)G::NPIX * G::P + 2 * (size_t)(G::CK / 4 + 1) * NB * 32 * 4);
-  const size_t epi_b = 4 * (size_t)64 * (NB * 32 + 4);
+  constexpr int BN = NB * (T16 ? 16 : 32);
+  const size_t main_b = 4 * ((size_t)G::NPIX * G::P + 2 * (size_t)(G::CK / 4 + 1) * BN * 4);
+  const size_t epi_b = 4 * (size_t)64 * (BN + 4);
   return main_b > epi_b ? main_b : epi_b;
 }
 
@@ -271,7 +317,18 @@ bool fp_conv3_eligible(const fp_op& op) {
   return (long)op.N * fp_ceil_div(op.OH, TH) * fp_ceil_div(op.OW, TW) >= 256;
 }
 
+// 16-column n tiles (v_mfma_f32_16x16x4_f32), stride 1, one chunk.  Measured at batch 256 (gpurun_out/r2_yp_m*.log,
+// summarised in DESIGN.md section 6): 48 -> 48 @ 80 x 80 1070 -> 636 us and 64 -> 64 @ 80 x 80 1282 -> 1041 us (117
+// TFLOP/s) against the 32 x 32 x 2 tiles; 24 -> 24 (2 tiles), 92 -> 92 (6 tiles) and the stride-2 128 -> 128 (8 tiles)
+// are 3-20 % slower that way and stay on 32-column tiles.
+bool fp_conv3_t16(const fp_op& op) {
+  if (op.stride != 1 || op.Cout > 112) return false;
+  if (op.Cout > 32 && op.Cout <= 64) return true;                           // 3 or 4 tiles of 16
+  return fp_round_up(op.Cout, 16) < fp_round_up(op.Cout, 32);               // a whole idle 16-column tile otherwise
+}
+
 int fp_conv3_nb(const fp_op& op) {
+  if (fp_conv3_t16(op)) return (int)fp_round_up(op.Cout, 16) / 16;          // 1, 3, 4, 5 or 7 tiles of 16
   const int nblk = (int)fp_round_up(op.Cout, 32) / 32;
   return nblk >= 4 ? 4 : nblk;   // wider outputs run as several 128-column chunks (grid.y)
 }
@@ -292,27 +349,37 @@ int fp_launch_conv3(const fp_op& op, const float* weights, float* arena, hipStre
   a.tiles_x = fp_ceil_div(op.OW, TW);
   a.tiles_per_img = a.tiles_x * fp_ceil_div(op.OH, TH);
   const int NB = fp_conv3_nb(op);
-  const dim3 grid((unsigned)((long)op.N * a.tiles_per_img), (unsigned)fp_ceil_div(a.Npad, NB * 32)), block(256);
+  const bool t16 = fp_conv3_t16(op);
+  const dim3 grid((unsigned)((long)op.N * a.tiles_per_img), (unsigned)(t16 ? fp_ceil_div((int)fp_round_up(op.Cout, 16), NB * 16) : fp_ceil_div(a.Npad, NB * 32))), block(256);
   hipError_t ae = hipSuccess;
-#define FP_CONV3_CASE(NBV, SV)                                                                                     \
+#define FP_CONV3_CASE(NBV, SV, T16V)                                                                               \
   {                                                                                                                \
-    const size_t lds = conv3_lds_bytes<NBV, SV>();                                                                 \
-    ae = hipFuncSetAttribute((const void*)conv3_kernel<NBV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (ae == hipSuccess) hipLaunchKernelGGL((conv3_kernel<NBV, SV>), grid, block, lds, s, a);                     \
+    const size_t lds = conv3_lds_bytes<NBV, SV, T16V>();                                                           \
+    ae = hipFuncSetAttribute((const void*)conv3_kernel<NBV, SV, T16V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                             (int)lds);                                                                            \
+    if (ae == hipSuccess) hipLaunchKernelGGL((conv3_kernel<NBV, SV, T16V>), grid, block, lds, s, a);               \
   }
-  if (op.stride == 1) {
+  if (t16) {
     switch (NB) {
-      case 1: FP_CONV3_CASE(1, 1) break;
-      case 2: FP_CONV3_CASE(2, 1) break;
-      case 3: FP_CONV3_CASE(3, 1) break;
-      default: FP_CONV3_CASE(4, 1) break;
+      case 1: FP_CONV3_CASE(1, 1, true) break;
+      case 3: FP_CONV3_CASE(3, 1, true) break;
+      case 4: FP_CONV3_CASE(4, 1, true) break;
+      case 5: FP_CONV3_CASE(5, 1, true) break;
+      default: FP_CONV3_CASE(7, 1, true) break;
+    }
+  } else if (op.stride == 1) {
+    switch (NB) {
+      case 1: FP_CONV3_CASE(1, 1, false) break;
+      case 2: FP_CONV3_CASE(2, 1, false) break;
+      case 3: FP_CONV3_CASE(3, 1, false) break;
+      default: FP_CONV3_CASE(4, 1, false) break;
     }
   } else {
     switch (NB) {
-      case 1: FP_CONV3_CASE(1, 2) break;
-      case 2: FP_CONV3_CASE(2, 2) break;
-      case 3: FP_CONV3_CASE(3, 2) break;
-      default: FP_CONV3_CASE(4, 2) break;
+      case 1: FP_CONV3_CASE(1, 2, false) break;
+      case 2: FP_CONV3_CASE(2, 2, false) break;
+      case 3: FP_CONV3_CASE(3, 2, false) break;
+      default: FP_CONV3_CASE(4, 2, false) break;
     }
   }
 #undef FP_CONV3_CASE

@@ -596,6 +596,10 @@ def test_yolo_letterbox_fused_into_stem_is_bit_exact(dev, frame_hw):
     (92, 92, (33, 37), 1, False, 24),     # odd k-quad count in the last slab, ragged 8 x 16 tiles
     (96, 184, (40, 40), 1, False, 24),    # two 128-column chunks (the second one partial)
     (24, 24, (32, 48), 1, True, 24),      # single n tile: two alternating partial sums
+    (48, 48, (40, 40), 1, True, 24),      # 16-column n tiles (16x16x4 MFMA): yolov5s C3 bottleneck, 3 tiles
+    (44, 12, (35, 33), 1, False, 24),     # 16-column tiles: one partial tile, short last slab, ragged spatial tiles
+    (72, 80, (32, 48), 1, False, 24),     # 16-column tiles: 5 tiles, slab of 8 channels (half a 16-channel group)
+    (36, 108, (32, 40), 1, False, 24),    # 16-column tiles: 7 tiles (last one partial), slab of one k-quad
     (128, 128, (64, 72), 2, False, 24),   # stride 2: even / odd column planes
     (132, 96, (66, 70), 2, False, 24),    # stride 2, last slab of one k-quad, ragged tiles
 ])
