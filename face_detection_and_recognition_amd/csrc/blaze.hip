@@ -34,6 +34,7 @@ struct BlazeArgs {
   int Kpad, Npad, OHW, C4, res_C;
   long M;
   int ntiles;
+  fp_divisor ohw_div, ow_div;   // persistent kernel: pixel index -> (image, y, x)
 };
 
 constexpr int TM = 128;
@@ -210,28 +211,54 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
 // Here a workgroup stages the weights ONCE and walks tiles t = k*G + swz(block); the 3 x (3S+3) window of the NEXT
 // tile is loaded into registers right after the current tile's depthwise values are in LDS, so its HBM latency
 // hides under the MFMAs, the epilogue and the stores.  One lane = one (4-pixel group, 4-channel group) item.
-template <int S>
+// CIN / COUT != 0 fix the widths at compile time (the 24 -> 24 blocks of the back model): every LDS stride becomes an
+// immediate and the k loop unrolls.
+//
+// Nothing in this kernel is saturated (rocprofv3 SQ counters: VALU ~36 % of a SIMD, MFMA pipe 21 %, HBM 3.5-3.9
+// TB/s): it is bound by the serial chain of one tile inside a workgroup, of which only 3 overlap on a CU.  Round 2
+// shortened that chain (ISA of the first version in DESIGN.md finding 12), 231 -> 208 us on the 128 x 128 blocks:
+//   * the window registers hold RAW loads; the zero padding is applied from a bit mask when the window is consumed,
+//     one tile later.  A select next to the load made every wave wait for its 18 loads inside the "prefetch";
+//   * the shortcut values are read from LDS in one batch before the epilogue arithmetic (an `if (has_sc) v += St[..]`
+//     per accumulator register had compiled to 16 exec-masked LDS round trips, each waited for on its own);
+//   * two MFMA accumulators (even / odd k steps): a 32x32x2 f32 MFMA that accumulates into the previous one's result
+//     issues at half rate;
+//   * pixel index -> (image, y, x) by multiply-high with host-computed reciprocals (fp_fastdiv) instead of two
+//     16-instruction integer divisions per tile; the pointwise bias comes from LDS (a global load first used inside
+//     the loop put a vmcnt(0) -- a wait for the prefetch -- into the epilogue);
+//   * the three waves that do the depthwise phase (192 of 256 lanes at 24 channels) rotate with the block index, so the
+//     idle role does not land on the same SIMD in every co-resident workgroup.
+// Measured and rejected: storing a tile after the NEXT tile's depthwise phase (so the stores are older than the prefetch
+// in the in-order vmcnt queue) together with the shortcut as identity rows of the GEMM (no shortcut tile, two barriers):
+// 228 us -- the doubled MFMA chain and LDS A traffic cost more than the store drain they avoid.
+template <int S, int CIN, int COUT>
 __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel(BlazeArgs p) {
   constexpr int WIN = 3 * S + 3;
+  const int Cin = CIN ? CIN : p.Cin, Cout = COUT ? COUT : p.Cout;
+  const int Kpad = CIN ? (CIN + 7) / 8 * 8 : p.Kpad;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LDT = p.Kpad + 4, LDS_ = p.Cin + 4;
+  const int LDT = Kpad + 4, LDS_ = Cin + 4;
   float* At = smem;                     // [TM][LDT]
   float* St = At + TM * LDT;            // [TM][LDS_]
   float* Ot = St + TM * LDS_;           // [TM][Cout]   (separate from At: one barrier less per tile)
-  float* Bs = Ot + TM * p.Cout;         // [Kpad/4][32][4]
-  float* Ws = Bs + p.Kpad * 32;         // [10][Cin]
+  float* Bs = Ot + TM * Cout;           // [Kpad/4][32][4]
+  float* Ws = Bs + Kpad * 32;           // [10][Cin]
+  float* Bp = Ws + 10 * Cin;            // [32] pointwise bias
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, h = lane >> 5;
 
-  for (int i = tid; i < (p.Kpad >> 2) * 32; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.wp + (long)i * 4);
-  for (int i = tid; i < (10 * p.Cin) >> 2; i += 256)
-    *(f32x4*)&Ws[i * 4] = (i * 4 < 9 * p.Cin) ? *(const f32x4*)(p.wd + (long)i * 4)
-                                              : *(const f32x4*)(p.bd + ((long)i * 4 - 9 * p.Cin));
+  if (tid < 32) Bp[tid] = tid < Cout ? p.bp[tid] : 0.f;
+  for (int i = tid; i < (Kpad >> 2) * 32; i += 256) *(f32x4*)&Bs[i * 4] = *(const f32x4*)(p.wp + (long)i * 4);
+  for (int i = tid; i < (10 * Cin) >> 2; i += 256)
+    *(f32x4*)&Ws[i * 4] = (i * 4 < 9 * Cin) ? *(const f32x4*)(p.wd + (long)i * 4)
+                                            : *(const f32x4*)(p.bd + ((long)i * 4 - 9 * Cin));
 
-  const int KC4 = p.Kpad >> 2;
-  const int g = tid / KC4, c4 = tid - g * KC4;
-  const bool in_tile = tid < (TM / 4) * KC4;
-  const bool active = in_tile && c4 < p.C4;
+  // depthwise items: (4-pixel group g, 4-channel group c4); the wave -> item-range map rotates with the block index
+  const int KC4 = Kpad >> 2;
+  const int dtid = (((wave - (int)(blockIdx.x >> 3) - (int)(blockIdx.x >> 8)) & 3) << 6) + lane;
+  const int g = dtid / KC4, c4 = dtid - g * KC4;
+  const bool in_tile = dtid < (TM / 4) * KC4;
+  const bool active = in_tile && c4 < (Cin >> 2);
   const int r = g * 4, c = c4 * 4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 
@@ -244,59 +271,78 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
   }
 
   // Window loads use 32-bit BYTE offsets from the (wave-uniform, SGPR) tensor base: one address register and one
-  // v_add_u32 per load instead of a 64-bit multiply-add each (the launcher checks the tensor is < 4 GiB).  The fused
-  // kernel is VALU-issue bound (~800 VALU instructions per 12 MFMAs), and address arithmetic was a
-  // quarter of them.
+  // v_add_u32 per load instead of a 64-bit multiply-add each (the launcher checks the tensor is < 4 GiB).
   const char* inb = (const char*)p.in;
+  const unsigned row_b = (unsigned)(p.W * p.in_ld) * 4u, px_b = (unsigned)p.in_ld * 4u;
   f32x4 x[3][WIN];
-  auto issue_loads = [&](long tile) {
-    long m = tile * TM + r;
-    m = m < p.M ? m : p.M - 4;
-    const unsigned mm = (unsigned)m;
-    const unsigned img = mm / (unsigned)p.OHW;
+  unsigned vmask = 0;                   // bits 0..2: row ky inside the map, bits 3..3+WIN-1: column j inside the map
+  auto issue_loads = [&](int tile) {
+    const unsigned mm = min((unsigned)tile * TM + (unsigned)r, (unsigned)p.M - 4u);
+    const unsigned img = fp_fastdiv(mm, p.ohw_div);
     const unsigned rem = mm - img * (unsigned)p.OHW;
-    const int oy = (int)(rem / (unsigned)p.OW), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
+    const int oy = (int)fp_fastdiv(rem, p.ow_div), ox = (int)(rem - (unsigned)oy * (unsigned)p.OW);
     const unsigned ib = (img * (unsigned)p.in_ns + (unsigned)c) * 4u;
-    const unsigned row_b = (unsigned)(p.W * p.in_ld) * 4u, px_b = (unsigned)p.in_ld * 4u;
     const int iy0 = S == 1 ? oy - 1 : 2 * oy, ix0 = S == 1 ? ox - 1 : 2 * ox;
     unsigned colo[WIN];
-    unsigned vx = 0;
+    unsigned vm = 0;
 #pragma unroll
     for (int j = 0; j < WIN; ++j) {
       const int ix = ix0 + j;
       colo[j] = (unsigned)min(max(ix, 0), p.W - 1) * px_b;
-      if ((unsigned)ix < (unsigned)p.W) vx |= 1u << j;
+      if ((unsigned)ix < (unsigned)p.W) vm |= 8u << j;
     }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = iy0 + ky;
-      const bool vy = (unsigned)iy < (unsigned)p.H;
+      if ((unsigned)iy < (unsigned)p.H) vm |= 1u << ky;
       const unsigned rowo = ib + (unsigned)min(max(iy, 0), p.H - 1) * row_b;
 #pragma unroll
-      for (int j = 0; j < WIN; ++j) {
-        const f32x4 t = *(const f32x4*)(inb + (rowo + colo[j]));
-        x[ky][j] = (vy && ((vx >> j) & 1u)) ? t : z;
-      }
+      for (int j = 0; j < WIN; ++j) x[ky][j] = *(const f32x4*)(inb + (rowo + colo[j]));
     }
+    vmask = vm;
+  };
+  auto store_tile = [&](int tile) {     // Ot -> the tile's contiguous byte range of the dense NHWC output
+    const long m0 = (long)tile * TM;
+    const long rows_left = p.M - m0;
+    const int n4 = (rows_left < TM ? (int)rows_left : TM) * Cout / 4;
+    float* obase = p.out + m0 * Cout;
+    for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
   };
 
-  long tile = pos;
+  int tile = pos;
   if (tile < p.ntiles && active) issue_loads(tile);
   __syncthreads();  // weights staged
-  const float bias_n = lr < p.Cout ? p.bp[lr] : 0.f;
-  for (long k = 0; tile < p.ntiles; ++k) {
+  const float bias_n = Bp[lr];
+  const bool has_sc = lr < p.res_C;
+  const int lrs = min(lr, p.res_C - 1);
+  while (tile < p.ntiles) {
     // depthwise + shortcut from the prefetched window
     if (active) {
-      f32x4 acc[4] = {z, z, z, z}, sc[4];
+      const f32x4 bias = *(const f32x4*)&Ws[9 * Cin + c];
+      f32x4 acc[4] = {bias, bias, bias, bias}, sc[4];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * p.Cin + c];
-        const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * p.Cin + c];
-        const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * p.Cin + c];
+        const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * Cin + c];
+        const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * Cin + c];
+        const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * Cin + c];
+        const bool vy = (vmask >> ky) & 1u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += x[ky][q * S] * w0 + x[ky][q * S + 1] * w1 + x[ky][q * S + 2] * w2;
+        for (int j = 0; j < WIN; ++j) {
+          // only the first and the last window column (stride 1) / the last one (stride 2) and the first / last row
+          // can lie outside the map; the shortcut taps (centre, 2x2 pool window) never do
+          const bool edge_col = S == 1 ? (j == 0 || j == WIN - 1) : (j == WIN - 1);
+          const bool edge_row = S == 1 ? ky != 1 : ky == 2;
+          if (edge_col && edge_row) x[ky][j] = (vy && ((vmask >> (3 + j)) & 1u)) ? x[ky][j] : z;
+          else if (edge_col) x[ky][j] = ((vmask >> (3 + j)) & 1u) ? x[ky][j] : z;
+          else if (edge_row) x[ky][j] = vy ? x[ky][j] : z;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // three statements: each contracts to one packed FMA on the accumulator
+          acc[q] += x[ky][q * S] * w0;
+          acc[q] += x[ky][q * S + 1] * w1;
+          acc[q] += x[ky][q * S + 2] * w2;
+        }
       }
-      const f32x4 bias = *(const f32x4*)&Ws[9 * p.Cin + c];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (S == 1) {
@@ -306,7 +352,7 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
           for (int e = 0; e < 4; ++e)  // rows 0,1 x cols 2q,2q+1 = the 2x2 max-pool window
             sc[q][e] = fmaxf(fmaxf(x[0][2 * q][e], x[0][2 * q + 1][e]), fmaxf(x[1][2 * q][e], x[1][2 * q + 1][e]));
         }
-        *(f32x4*)&At[(r + q) * LDT + c] = acc[q] + bias;
+        *(f32x4*)&At[(r + q) * LDT + c] = acc[q];
         *(f32x4*)&St[(r + q) * LDS_ + c] = sc[q];
       }
     } else if (in_tile) {
@@ -314,38 +360,43 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
       for (int q = 0; q < 4; ++q) *(f32x4*)&At[(r + q) * LDT + c] = z;  // zero padding columns of the K dimension
     }
     __syncthreads();
-    const long next = (k + 1) * G + pos;
-    if (next < p.ntiles && active) issue_loads(next);  // in flight during MFMA + epilogue + stores
+    const int next = tile + G;
+    if (next < p.ntiles && active) issue_loads(next);  // in flight during MFMA, epilogue and the stores
 
-    f32x16 macc;
+    f32x16 m0, m1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) macc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) m0[i] = bias_n, m1[i] = 0.f;   // pointwise bias as the accumulator's start value
     const float* arow = &At[(wave * 32 + lr) * LDT + 4 * h];
-    for (int kq = 0; kq < (p.Kpad >> 3); ++kq) {
+    for (int kq = 0; kq < (Kpad >> 3); ++kq) {
       const f32x4 a = *(const f32x4*)(arow + kq * 8);
       const f32x4 b = *(const f32x4*)&Bs[((kq * 2 + h) * 32 + lr) * 4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], macc, 0, 0, 0);
+      m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], m0, 0, 0, 0);
+      FP_MFMA_ORDER();
+      m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], m1, 0, 0, 0);
+      FP_MFMA_ORDER();
+      m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], m0, 0, 0, 0);
+      FP_MFMA_ORDER();
+      m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], m1, 0, 0, 0);
+      FP_MFMA_ORDER();
     }
-    if (lr < p.Cout) {
-      const bool has_sc = lr < p.res_C;
+    {
+      // shortcut values of this lane's 16 (row, column lr) outputs: one batch of unconditional LDS reads from a
+      // clamped column, selected below; then the arithmetic
+      float sv[16];
+      const float* srow = &St[(wave * 32 + 4 * h) * LDS_ + lrs];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        float v = macc[reg] + bias_n;
-        if (has_sc) v += St[row * LDS_ + lr];
-        Ot[row * p.Cout + lr] = v > 0.f ? v : 0.f;
+      for (int reg = 0; reg < 16; ++reg) sv[reg] = srow[((reg & 3) + 8 * (reg >> 2)) * LDS_];
+      if (lr < Cout) {
+        float* orow = &Ot[(wave * 32 + 4 * h) * Cout + lr];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const float v = (m0[reg] + m1[reg]) + (has_sc ? sv[reg] : 0.f);
+          orow[((reg & 3) + 8 * (reg >> 2)) * Cout] = v > 0.f ? v : 0.f;
+        }
       }
     }
     __syncthreads();  // Ot complete; At / St free for the next tile
-    {
-      const long m0 = tile * TM;
-      const long rows_left = p.M - m0;
-      const int nrows = rows_left < TM ? (int)rows_left : TM;
-      const int n4 = nrows * p.Cout / 4;
-      float* obase = p.out + m0 * p.Cout;
-      for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
-    }
+    store_tile(tile);
     tile = next;
   }
 }
@@ -358,6 +409,8 @@ size_t fp_blazeblock_lds_bytes(int Cin, int Cout) {
   const size_t a = (size_t)TM * (LDT > Cout ? LDT : Cout);
   return 4 * (a + (size_t)TM * (Cin + 4) + (size_t)Kpad * Npad + (size_t)10 * Cin);
 }
+
+bool fp_blazeblock_fixed24(const fp_op& op) { return op.Cin == 24 && op.Cout == 24; }
 
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
   // op fields: w_off = depthwise weights [9][Cin], scale_off = depthwise bias, slope_off = packed pointwise
@@ -391,13 +444,21 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
       (unsigned long long)op.N * (unsigned long long)op.in_ns * 4ull < (1ull << 32)) {   // 32-bit byte offsets
     // persistent kernel: 3 (stride 1) / 2 (stride 2) resident workgroups per CU, each striding over the tiles
     const size_t plds = 4 * ((size_t)TM * (a.Kpad + 4) + (size_t)TM * (op.Cin + 4) + (size_t)TM * op.Cout +
-                             (size_t)a.Kpad * 32 + (size_t)10 * op.Cin);
+                             (size_t)a.Kpad * 32 + (size_t)10 * op.Cin + 32);
     const int per_cu = op.stride == 1 ? 3 : 2;
     int G = 256 * per_cu;
     if (G > a.ntiles) G = a.ntiles;
     if (plds <= 64 * 1024) {
-      if (op.stride == 1) hipLaunchKernelGGL((blazeblock_persist_kernel<1>), dim3(G), dim3(256), plds, s, a);
-      else hipLaunchKernelGGL((blazeblock_persist_kernel<2>), dim3(G), dim3(256), plds, s, a);
+      a.ohw_div = fp_make_divisor((unsigned)a.OHW);
+      a.ow_div = fp_make_divisor((unsigned)op.OW);
+      const bool w24 = fp_blazeblock_fixed24(op);
+      if (op.stride == 1) {
+        if (w24) hipLaunchKernelGGL((blazeblock_persist_kernel<1, 24, 24>), dim3(G), dim3(256), plds, s, a);
+        else hipLaunchKernelGGL((blazeblock_persist_kernel<1, 0, 0>), dim3(G), dim3(256), plds, s, a);
+      } else {
+        if (w24) hipLaunchKernelGGL((blazeblock_persist_kernel<2, 24, 24>), dim3(G), dim3(256), plds, s, a);
+        else hipLaunchKernelGGL((blazeblock_persist_kernel<2, 0, 0>), dim3(G), dim3(256), plds, s, a);
+      }
       FP_CHECK_LAUNCH();
       return FP_OK;
     }

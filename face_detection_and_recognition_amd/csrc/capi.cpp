@@ -179,7 +179,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
     case FP_OP_BLAZEBLOCK:
       if (fp_round_up(op->Cin, 8) <= 32 && fp_round_up(op->Cout, 32) == 32 &&
           fp_ceil_div((long)op->N * op->OH * op->OW, 128) >= 2048)
-        snprintf(buf, sizeof(buf), "blazeblock_persist_kernel<%d>", op->stride);
+        snprintf(buf, sizeof(buf), "blazeblock_persist_kernel<%d, %s>", op->stride, fp_blazeblock_fixed24(*op) ? "24, 24" : "0, 0");
       else
         snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
       return buf;

@@ -37,6 +37,22 @@ void fp_set_hip_error(hipError_t e);
     }                                             \
   } while (0)
 
+// n / d by multiply-high for 0 <= n < 2^31 and d >= 2: with s = ceil(log2 d), k = 31 + s and M = floor(2^k / d) + 1
+// (M < 2^32 because d > 2^(s-1)), floor(n * M / 2^k) = floor(n / d): the error M*d - 2^k lies in (0, d], and
+// n * d < 2^31 * 2^s = 2^k.  Device side: __umulhi(n, M) >> (s - 1).
+struct fp_divisor {
+  unsigned mul, shift;
+};
+static inline fp_divisor fp_make_divisor(unsigned d) {
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  fp_divisor r;
+  r.mul = (unsigned)((1ull << (31 + s)) / d + 1ull);
+  r.shift = s - 1;   // d >= 2 -> s >= 1
+  return r;
+}
+__device__ __forceinline__ unsigned fp_fastdiv(unsigned n, fp_divisor d) { return __umulhi(n, d.mul) >> d.shift; }
+
 static inline int fp_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long fp_round_up(long a, long b) { return (a + b - 1) / b * b; }
 
@@ -48,6 +64,7 @@ int fp_launch_upsample2x(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_blazeblock_fixed24(const fp_op& op);   // persistent BlazeBlock instantiated with compile-time 24 -> 24 widths
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel, false: dwpw_kernel
 bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take the wave-private streaming kernel
