@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfacepath.so")
 
 FP_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -20,6 +20,7 @@ OP_YSTEM_U8, OP_STEM_U8 = 10, 11
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
 # fp_res_mode
 RES_NONE, RES_ADD_BEFORE_ACT, RES_ADD_AFTER_ACT, RES_POOL2_BEFORE_ACT, RES_SHUFFLE2 = 0, 1, 2, 3, 4
+OPF_IN_ROWPAD, OPF_OUT_ROWPAD = 1, 2   # fp_op.flags: row-padded input / output view (include/facepath.h)
 
 
 class FpOp(C.Structure):
@@ -37,7 +38,7 @@ class FpOp(C.Structure):
         ("in_ns", C.c_int64), ("out_ns", C.c_int64), ("res_ns", C.c_int64),
         ("in_off", C.c_int64), ("out_off", C.c_int64), ("res_off", C.c_int64),
         ("w_off", C.c_int64), ("scale_off", C.c_int64), ("bias_off", C.c_int64), ("slope_off", C.c_int64),
-        ("act2", C.c_int32), ("reserved", C.c_int32),
+        ("act2", C.c_int32), ("flags", C.c_int32),
     ]
 
 

@@ -35,6 +35,7 @@ struct BlazeArgs {
   long M;
   int ntiles;
   fp_divisor ohw_div, ow_div;   // persistent kernel: pixel index -> (image, y, x)
+  int out_rowpad;               // persistent kernel: output in the row-padded layout
 };
 
 constexpr int TM = 128;
@@ -200,8 +201,19 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
     const long rows_left = p.M - m0;
     const int nrows = rows_left < TM ? (int)rows_left : TM;
     const int n4 = nrows * p.Cout / 4;
-    float* obase = p.out + m0 * p.Cout;
-    for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+    if (!p.out_rowpad) {
+      float* obase = p.out + m0 * p.Cout;
+      for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+    } else {   // row-padded output (facepath.h FP_OPF_OUT_ROWPAD)
+      const int q4 = p.Cout >> 2;
+      for (int i = tid; i < n4; i += 256) {
+        const unsigned px = (unsigned)i / (unsigned)q4, cq = (unsigned)i - px * (unsigned)q4;
+        const unsigned m = (unsigned)m0 + px;
+        const unsigned img = fp_fastdiv(m, p.ohw_div), rem = m - img * (unsigned)p.OHW;
+        const unsigned oy = fp_fastdiv(rem, p.ow_div);
+        *(f32x4*)(p.out + (long)img * p.out_ns + ((long)rem + oy) * p.Cout + cq * 4) = *(const f32x4*)&Ot[i * 4];
+      }
+    }
   }
 }
 
@@ -305,8 +317,19 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
     const long m0 = (long)tile * TM;
     const long rows_left = p.M - m0;
     const int n4 = (rows_left < TM ? (int)rows_left : TM) * Cout / 4;
-    float* obase = p.out + m0 * Cout;
-    for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+    if (!p.out_rowpad) {
+      float* obase = p.out + m0 * Cout;
+      for (int i = tid; i < n4; i += 256) *(f32x4*)(obase + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+    } else {                            // row-padded output (facepath.h FP_OPF_OUT_ROWPAD): one more pixel per row
+      const int q4 = Cout >> 2;
+      for (int i = tid; i < n4; i += 256) {
+        const unsigned px = (unsigned)i / (unsigned)q4, cq = (unsigned)i - px * (unsigned)q4;
+        const unsigned m = (unsigned)m0 + px;
+        const unsigned img = fp_fastdiv(m, p.ohw_div), rem = m - img * (unsigned)p.OHW;
+        const unsigned oy = fp_fastdiv(rem, p.ow_div);
+        *(f32x4*)(p.out + (long)img * p.out_ns + ((long)rem + oy) * Cout + cq * 4) = *(const f32x4*)&Ot[i * 4];
+      }
+    }
   };
 
   int tile = pos;
@@ -401,6 +424,218 @@ __global__ __launch_bounds__(256, S == 1 ? 3 : 2) void blazeblock_persist_kernel
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-private BlazeBlock, stride 1, C -> C channels, on a ROW-PADDED input (facepath.h FP_OPF_IN_ROWPAD: every image
+// row is followed by one zero pixel, the image by a zero row above and below; (y, -1) is the pad pixel of row y - 1).
+//
+// The persistent kernel above synchronises four waves twice per tile and spends ~390 VALU instructions per wave and
+// tile, most of them on what the padded layout makes unnecessary: clamps, validity masks and selects for the zero
+// padding, per-lane index decode.  With no memory traffic at all its skeleton still takes 140 of its 207 us on the
+// 128 x 128 blocks (lab toggles, DESIGN.md finding 14).  Here
+//   * a WAVE owns a tile of 32 consecutive pixels of one image row and runs the whole chain on it with its own LDS
+//     region: window -> depthwise (48 of 64 lanes = 8 pixel groups x 6 channel groups) -> A tile -> 12 MFMAs against
+//     the 1x1 weights held in registers -> shortcut + ReLU -> output tile -> 3 x 16-byte stores per lane.  No
+//     __syncthreads() in the loop: LDS executes one wave's instructions in order, and the 12 waves of a CU interleave
+//     freely instead of meeting at barriers;
+//   * the tile index is wave-uniform, so (image, row, column) and the row base pointers are SALU work; a load or store
+//     is `global_* v, v_lane_offset, s[base] offset:imm` with a lane offset computed once per kernel.  The zero
+//     padding is in memory: no clamps, no masks, no selects;
+//   * the next tile's window is requested right after the depthwise phase has consumed the current one; the previous
+//     tile's output leaves LDS just before that request (older than the prefetch in the in-order vmcnt queue, so the
+//     wait for the window does not drain stores that were only just issued).
+// The output is written row-padded or dense (out_rp / out_ns), so a chain of blocks keeps the layout and the last one
+// hands a dense tensor to the next kernel.
+struct BlazeWpArgs {
+  const float* in;    // pixel (0, 0) of image 0
+  float* out;
+  const float* wd;    // [9][C]
+  const float* bd;    // [C]
+  const float* wp;    // packed [C/4][32][4]
+  const float* bp;    // [C]
+  int OH, OW, strips, bands, ntiles;   // tile = (image, band of R rows, strip of 32 columns)
+  int in_rp, out_rp;  // row pitch, floats
+  long in_ns, out_ns;
+  fp_divisor strips_div, bands_div;
+};
+
+// R = rows a wave marches down per tile.  The window is a ring of three input rows in registers: a new output row costs
+// ONE new row of 6 loads instead of 18 (R = 4: 9 loads per output row on average).  The window loads, not HBM, were
+// the slow part of the first form of this kernel: with the compute stripped it took 150 us to read a 403 MB tensor that
+// a linear read gets through in 107 us -- 4.5 16-byte requests per output (pixel, channel-quad) in 96-byte pieces keep
+// the CU's address/L1 path busy, and 12 waves x 10 KB of window do not fit the 32 KB L1 (DESIGN.md finding 14).
+template <int C, int R>
+__global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
+  static_assert(C % 8 == 0 && C <= 32, "one 32-column n tile, K a multiple of 8");
+  constexpr int LDT = C + 4, C4 = C / 4, NIT = 8 * C4, KG = C / 8;
+  constexpr int WAVE_FLOATS = 2 * 32 * LDT + 32 * C;      // A tile, shortcut tile, output tile
+  constexpr int NST = (32 * C / 4) / 64;                   // 16-byte stores per lane and row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                                        // [10][C] depthwise taps + bias
+  float* Bp = Ws + 10 * C;                                 // [32]
+  float* Wv = Bp + 32;                                     // 4 wave regions (first used to stage the 1x1 weights)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+
+  for (int i = tid; i < (10 * C) / 4; i += 256)
+    *(f32x4*)&Ws[i * 4] = (i * 4 < 9 * C) ? *(const f32x4*)(p.wd + i * 4) : *(const f32x4*)(p.bd + (i * 4 - 9 * C));
+  if (tid < 32) Bp[tid] = tid < C ? p.bp[tid] : 0.f;
+  for (int i = tid; i < KG * 2 * 32; i += 256) *(f32x4*)&Wv[i * 4] = *(const f32x4*)(p.wp + i * 4);
+  __syncthreads();
+  f32x4 bfrag[KG];                                         // this lane's B fragments: k-quad 2*kq + h, column lr
+#pragma unroll
+  for (int kq = 0; kq < KG; ++kq) bfrag[kq] = *(const f32x4*)&Wv[((kq * 2 + h) * 32 + lr) * 4];
+  __syncthreads();                                         // staging area becomes the wave regions
+
+  float* At = Wv + wv * WAVE_FLOATS;                       // [32][LDT]
+  float* St = At + 32 * LDT;                               // [32][LDT]
+  float* Ot = St + 32 * LDT;                               // [32][C]
+
+  // depthwise item of this lane: pixels 4g .. 4g+3 of the strip, channels 4c4 .. 4c4+3 (lanes >= NIT repeat item 0
+  // and write nothing)
+  const bool dw_lane = lane < NIT;
+  const int la = dw_lane ? lane : 0;
+  const int g = la / C4, c4 = la - g * C4;
+  const unsigned voff_in = (unsigned)((4 * g * C + 4 * c4) * 4);
+  const unsigned voff_out = (unsigned)lane * 16u;
+  const float* wl = &Ws[4 * c4];                           // this lane's taps [k][4] at wl + k*C, bias at k = 9
+  const f32x4 pbias = *(const f32x4*)&Bp[4 * c4];          // pointwise bias of this lane's channels: rides the shortcut
+
+  // XCD-aware order: block b runs on XCD b % 8; each XCD gets a contiguous range of every round's tiles, so the bands
+  // above and below a tile (its halo rows) are fetched into the same L2
+  const int G = gridDim.x, GW = G * 4;
+  int pos;
+  {
+    const int b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
+    pos = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+
+  // byte offsets from p.in / p.out, all scalar: window origin (y0 - 1, x0 - 1) and first output pixel of a tile
+  const char* inb = (const char*)p.in;
+  char* outb = (char*)p.out;
+  auto locate = [&](int t, long& ip, long& op) {
+    const unsigned bg = fp_fastdiv((unsigned)t, p.strips_div), sx = (unsigned)t - bg * (unsigned)p.strips;
+    const unsigned img = fp_fastdiv(bg, p.bands_div), y0 = (bg - img * (unsigned)p.bands) * R;
+    ip = fp_uniform(((long)img * p.in_ns + ((long)y0 - 1) * p.in_rp + ((long)sx * 32 - 1) * C) * 4);
+    op = fp_uniform(((long)img * p.out_ns + (long)y0 * p.out_rp + (long)sx * 32 * C) * 4);
+  };
+  f32x4 x[3][6];                                           // ring of three input rows
+  const long in_rb = (long)p.in_rp * 4, out_rb = (long)p.out_rp * 4;
+
+  int t = pos * 4 + wv;
+  long in_px = 0;               // byte offset of the current tile's window origin
+  long out_px = 0;              // ... of its first output pixel
+  long st_px = 0;               // ... of the row waiting in Ot
+  if (t < p.ntiles) {
+    locate(t, in_px, out_px);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const char* rowp = inb + fp_uniform(in_px + ky * in_rb);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) x[ky][j] = *(const f32x4*)(rowp + voff_in + j * C * 4);
+    }
+  }
+  bool have_prev = false;
+  while (t < p.ntiles) {
+    const int tn = t + GW;
+    long in_nx = 0, out_nx = 0;
+    if (tn < p.ntiles) locate(tn, in_nx, out_nx);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int s0 = r % 3, s1 = (r + 1) % 3, s2 = (r + 2) % 3;   // ring slots of rows y - 1, y, y + 1 (static: unrolled)
+      // ---- depthwise + shortcut -> A, S (this wave's region) ----
+      {
+        const f32x4 dbias = *(const f32x4*)(wl + 9 * C);
+        f32x4 acc[4] = {dbias, dbias, dbias, dbias};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int sl = ky == 0 ? s0 : ky == 1 ? s1 : s2;
+          const f32x4 w0 = *(const f32x4*)(wl + (ky * 3 + 0) * C);
+          const f32x4 w1 = *(const f32x4*)(wl + (ky * 3 + 1) * C);
+          const f32x4 w2 = *(const f32x4*)(wl + (ky * 3 + 2) * C);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {   // three statements: each contracts to one packed FMA on the accumulator
+            acc[q] += x[sl][q] * w0;
+            acc[q] += x[sl][q + 1] * w1;
+            acc[q] += x[sl][q + 2] * w2;
+          }
+        }
+        if (dw_lane) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            *(f32x4*)&At[(4 * g + q) * LDT + 4 * c4] = acc[q];
+            *(f32x4*)&St[(4 * g + q) * LDT + 4 * c4] = x[s1][q + 1] + pbias;   // shortcut = the centre tap (+ 1x1 bias)
+          }
+        }
+      }
+      // ---- previous row's output: LDS -> HBM, then the next window row(s) ----
+      if (have_prev) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j)
+          *(f32x4*)(outb + st_px + voff_out + j * 1024) = *(const f32x4*)&Ot[(lane + 64 * j) * 4];
+      }
+      st_px = fp_uniform(out_px + r * out_rb);
+      if (r + 1 < R) {                  // row y + 2 replaces row y - 1 in the ring
+        const char* rowp = inb + fp_uniform(in_px + (r + 3) * in_rb);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x[s0][j] = *(const f32x4*)(rowp + voff_in + j * C * 4);
+      } else if (tn < p.ntiles) {       // last row of the band: the next tile's first three rows
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const char* rowp = inb + fp_uniform(in_nx + ky * in_rb);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) x[ky][j] = *(const f32x4*)(rowp + voff_in + j * C * 4);
+        }
+      }
+      // ---- 1x1 on the MFMA pipe ----
+      f32x16 m0, m1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m0[i] = 0.f, m1[i] = 0.f;
+      const float* arow = &At[lr * LDT + 4 * h];
+#pragma unroll
+      for (int kq = 0; kq < KG; ++kq) {
+        const f32x4 a = *(const f32x4*)(arow + kq * 8);
+        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bfrag[kq][0], m0, 0, 0, 0);
+        FP_MFMA_ORDER();
+        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bfrag[kq][1], m1, 0, 0, 0);
+        FP_MFMA_ORDER();
+        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bfrag[kq][2], m0, 0, 0, 0);
+        FP_MFMA_ORDER();
+        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bfrag[kq][3], m1, 0, 0, 0);
+        FP_MFMA_ORDER();
+      }
+      // ---- shortcut + ReLU -> output tile (two halves: 8 shortcut values in flight, not 16 -- register budget) ----
+      {
+        const float* srow = &St[(4 * h) * LDT + (lr < C ? lr : 0)];
+        float* orow = &Ot[(4 * h) * C + lr];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float sv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sv[i] = srow[((i & 3) + 8 * (2 * half + (i >> 2))) * LDT];
+          if (lr < C) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int reg = 8 * half + i;
+              const float v = (m0[reg] + m1[reg]) + sv[i];
+              orow[((i & 3) + 8 * (2 * half + (i >> 2))) * C] = v > 0.f ? v : 0.f;
+            }
+          }
+        }
+      }
+      have_prev = true;
+    }
+    t = tn;
+    in_px = in_nx;
+    out_px = out_nx;
+  }
+  if (have_prev) {
+#pragma unroll
+    for (int j = 0; j < NST; ++j) *(f32x4*)(outb + st_px + voff_out + j * 1024) = *(const f32x4*)&Ot[(lane + 64 * j) * 4];
+  }
+}
+
 }  // namespace
 
 size_t fp_blazeblock_lds_bytes(int Cin, int Cout) {
@@ -412,12 +647,56 @@ size_t fp_blazeblock_lds_bytes(int Cin, int Cout) {
 
 bool fp_blazeblock_fixed24(const fp_op& op) { return op.Cin == 24 && op.Cout == 24; }
 
+// Wave-private kernel: stride 1, 24 -> 24 with the full shortcut, rows that split into 32-pixel tiles, row-padded input.
+bool fp_blazeblock_wp_eligible(const fp_op& op) {
+  return op.kind == FP_OP_BLAZEBLOCK && (op.flags & FP_OPF_IN_ROWPAD) && op.stride == 1 && op.KH == 3 && op.KW == 3 &&
+         op.Cin == 24 && op.Cout == 24 && op.res_C == 24 && op.in_ld == 24 && op.out_ld == 24 && op.out_cmul == 1 &&
+         op.OH == op.H && op.OW == op.W && op.OW % 32 == 0 && op.OW >= 64 && op.OH % 4 == 0 && op.OH >= 8 &&
+         op.in_off % 4 == 0 && op.out_off % 4 == 0 &&
+         op.in_ns % 4 == 0 && op.out_ns % 4 == 0 && (long)op.N * (op.OH / 4) * (op.OW / 32) < (1L << 31);
+}
+
+static int launch_blazeblock_wp(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  constexpr int C = 24, R = 4;
+  BlazeWpArgs a;
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.wd = weights + op.w_off;
+  a.bd = weights + op.scale_off;
+  a.wp = weights + op.slope_off;
+  a.bp = weights + op.bias_off;
+  a.OH = op.OH; a.OW = op.OW;
+  a.strips = op.OW / 32;            // >= 2 (eligibility: OW >= 64)
+  a.bands = op.OH / R;              // >= 2 (eligibility: OH % 4 == 0, OH >= 8)
+  a.ntiles = op.N * a.bands * a.strips;
+  a.in_rp = (op.W + 1) * C;
+  a.out_rp = (op.OW + ((op.flags & FP_OPF_OUT_ROWPAD) ? 1 : 0)) * C;
+  a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  a.strips_div = fp_make_divisor((unsigned)a.strips);
+  a.bands_div = fp_make_divisor((unsigned)a.bands);
+  const size_t lds = 4 * ((size_t)10 * C + 32 + 4 * (size_t)(2 * 32 * (C + 4) + 32 * C));
+  // persistent grid: at most 3 workgroups per CU, and no more than gives every wave the same number of tiles when
+  // the tile count allows it (a wave with one tile more than the others sets the kernel's length)
+  int G = fp_ceil_div(a.ntiles, 4);
+  if (G > 256 * 3) {
+    const int per_wave = fp_ceil_div(a.ntiles, 256 * 3 * 4);
+    G = fp_ceil_div(a.ntiles, 4 * per_wave);
+  }
+  hipLaunchKernelGGL((blazeblock_wp_kernel<C, R>), dim3(G), dim3(256), lds, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
   // op fields: w_off = depthwise weights [9][Cin], scale_off = depthwise bias, slope_off = packed pointwise
   // weights, bias_off = pointwise bias; res_C = channels of the shortcut (= logical Cin).
   if (op.KH != 3 || op.KW != 3 || (op.stride != 1 && op.stride != 2)) return FP_ERR_UNSUPPORTED;
+  if (op.flags & FP_OPF_IN_ROWPAD)
+    return fp_blazeblock_wp_eligible(op) ? launch_blazeblock_wp(op, weights, arena, s) : FP_ERR_UNSUPPORTED;
   if (op.Cin % 4 || op.Cout % 4 || op.in_ld % 4 || op.in_off % 4 || op.in_ns % 4 || op.out_off % 4) return FP_ERR_ALIGNMENT;
-  if (op.out_cmul != 1 || op.out_ld != op.Cout || op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return FP_ERR_UNSUPPORTED;
+  const bool out_rowpad = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
+  if (op.out_cmul != 1 || op.out_ld != op.Cout || (!out_rowpad && op.out_ns != (int64_t)op.OH * op.OW * op.Cout))
+    return FP_ERR_UNSUPPORTED;
   if (op.stride == 1 && (op.OH != op.H || op.OW != op.W)) return FP_ERR_INVALID_ARG;
   if (op.stride == 2 && (op.H % 2 || op.W % 2 || op.OH != op.H / 2 || op.OW != op.W / 2)) return FP_ERR_INVALID_ARG;
   if (op.Cout > 128 || op.res_C > op.Cin || op.OW % 4) return FP_ERR_UNSUPPORTED;
@@ -440,6 +719,9 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
   a.M = (long)op.N * a.OHW;
   if (a.M >= (1L << 31)) return FP_ERR_UNSUPPORTED;
   a.ntiles = fp_ceil_div(a.M, TM);
+  a.out_rowpad = out_rowpad;
+  a.ohw_div = fp_make_divisor((unsigned)a.OHW);   // OHW >= 4, OW >= 4 (OW % 4 == 0 above)
+  a.ow_div = fp_make_divisor((unsigned)op.OW);
   if (a.Kpad <= 32 && a.Npad == 32 && a.ntiles >= 2048 &&
       (unsigned long long)op.N * (unsigned long long)op.in_ns * 4ull < (1ull << 32)) {   // 32-bit byte offsets
     // persistent kernel: 3 (stride 1) / 2 (stride 2) resident workgroups per CU, each striding over the tiles
@@ -449,8 +731,6 @@ int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hi
     int G = 256 * per_cu;
     if (G > a.ntiles) G = a.ntiles;
     if (plds <= 64 * 1024) {
-      a.ohw_div = fp_make_divisor((unsigned)a.OHW);
-      a.ow_div = fp_make_divisor((unsigned)op.OW);
       const bool w24 = fp_blazeblock_fixed24(op);
       if (op.stride == 1) {
         if (w24) hipLaunchKernelGGL((blazeblock_persist_kernel<1, 24, 24>), dim3(G), dim3(256), plds, s, a);

@@ -44,15 +44,34 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
                     op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
+  // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
+  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD)) return FP_ERR_INVALID_ARG;
+  const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
+  if (in_rp && !fp_blazeblock_wp_eligible(op)) return FP_ERR_UNSUPPORTED;
+  if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_STEM_U8 || (op.kind == FP_OP_CONV && fp_stem_eligible(op))))
+    return FP_ERR_UNSUPPORTED;
+  if (out_rp && (op.out_cmul != 1 || op.out_ld != Cout)) return FP_ERR_UNSUPPORTED;
   // input extent
-  const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
-  if (!ext_in && !span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
+  if (in_rp) {
+    const int64_t lead = (int64_t)(op.W + 2) * op.in_ld;
+    if (op.in_ns < ((int64_t)(op.H + 2) * (op.W + 1) + 1) * op.in_ld) return FP_ERR_INVALID_ARG;
+    if (op.in_off < lead || !span_ok(op.in_off - lead, (int64_t)op.N * op.in_ns, arena_floats)) return FP_ERR_BOUNDS;
+  } else {
+    const int64_t in_ext = (int64_t)(op.N - 1) * op.in_ns + ((int64_t)op.H * op.W - 1) * op.in_ld + op.Cin;
+    if (!ext_in && !span_ok(op.in_off, in_ext, arena_floats)) return FP_ERR_BOUNDS;
+  }
   if (ext_in && op.in_off < 0) return FP_ERR_INVALID_ARG;
   const int64_t out_ch = ((op.kind == FP_OP_CONV || op.kind == FP_OP_DWPW) && op.res_mode == FP_RES_SHUFFLE2)
                              ? 2 * (int64_t)Cout : Cout;
-  const int64_t out_ext =
-      (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (out_ch - 1) * op.out_cmul + 1;
-  if (!span_ok(op.out_off, out_ext, arena_floats)) return FP_ERR_BOUNDS;
+  if (out_rp) {
+    const int64_t lead = (int64_t)(OW + 2) * op.out_ld;
+    if (op.out_ns < ((int64_t)(OH + 2) * (OW + 1) + 1) * op.out_ld) return FP_ERR_INVALID_ARG;
+    if (op.out_off < lead || !span_ok(op.out_off - lead, (int64_t)op.N * op.out_ns, arena_floats)) return FP_ERR_BOUNDS;
+  } else {
+    const int64_t out_ext =
+        (int64_t)(op.N - 1) * op.out_ns + ((int64_t)OH * OW - 1) * op.out_ld + (out_ch - 1) * op.out_cmul + 1;
+    if (!span_ok(op.out_off, out_ext, arena_floats)) return FP_ERR_BOUNDS;
+  }
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
@@ -177,6 +196,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
               op->out_off % 4 == 0 && op->in_ns % 4 == 0 && op->out_ns % 4 == 0) ? "copy4_kernel" : "copy_kernel";
     case FP_OP_L2NORM: return "l2norm_kernel";
     case FP_OP_BLAZEBLOCK:
+      if (op->flags & FP_OPF_IN_ROWPAD) return "blazeblock_wp_kernel<24>";
       if (fp_round_up(op->Cin, 8) <= 32 && fp_round_up(op->Cout, 32) == 32 &&
           fp_ceil_div((long)op->N * op->OH * op->OW, 128) >= 2048)
         snprintf(buf, sizeof(buf), "blazeblock_persist_kernel<%d, %s>", op->stride, fp_blazeblock_fixed24(*op) ? "24, 24" : "0, 0");

@@ -53,6 +53,16 @@ static inline fp_divisor fp_make_divisor(unsigned d) {
 }
 __device__ __forceinline__ unsigned fp_fastdiv(unsigned n, fp_divisor d) { return __umulhi(n, d.mul) >> d.shift; }
 
+// A 64-bit offset the caller knows to be wave-uniform, rebuilt from readfirstlane'd halves so that the compiler keeps
+// it in SGPRs: base + offset stays a scalar address and `global_load v, v_offset32, s[addr:addr+1] offset:imm` needs no
+// 64-bit vector address arithmetic.  (Offsets, not pointers: an integer -> pointer cast loses the global address space
+// and turns the accesses into flat_load / flat_store.)
+__device__ __forceinline__ long fp_uniform(long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long)(((unsigned long long)hi << 32) | lo);
+}
+
 static inline int fp_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long fp_round_up(long a, long b) { return (a + b - 1) / b * b; }
 
@@ -64,6 +74,7 @@ int fp_launch_upsample2x(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_blazeblock_wp_eligible(const fp_op& op);   // row-padded input: the wave-private kernel takes it
 bool fp_blazeblock_fixed24(const fp_op& op);   // persistent BlazeBlock instantiated with compile-time 24 -> 24 widths
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel, false: dwpw_kernel

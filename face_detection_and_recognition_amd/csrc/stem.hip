@@ -28,7 +28,9 @@ struct StemArgs {
   const float* bias;
   const float* slope;
   int H, W, OH, OW, OHW, Cout, Npad, Kpad, act, pad_t, pad_l, Wp, rows_max, tiles_per_img, ntiles;
-  long in_ns;
+  long in_ns, out_ns;
+  int out_rowpad;            // output in the row-padded layout (facepath.h)
+  fp_divisor q4_div, ow_div;
   // U8 input: the H x W image is a letterbox canvas resampled from u8 frames while it is staged (letterbox.h)
   const uint8_t* frames;
   const fp_lb_tap* tabs;     // [W] column taps, [H] row taps, trailer {pad colour, swap R/B}
@@ -182,9 +184,19 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
     // would otherwise also wait for those stores (vmcnt counts both)
     if (next < p.ntiles) write_stage();
     {
-      float* ob = p.out + ((long)img * p.OHW + m_lo) * p.Cout;
       const int n4 = nvalid * p.Cout / 4;
-      for (int i = tid; i < n4; i += 256) *(f32x4*)(ob + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+      if (!p.out_rowpad) {
+        float* ob = p.out + ((long)img * p.OHW + m_lo) * p.Cout;
+        for (int i = tid; i < n4; i += 256) *(f32x4*)(ob + (long)i * 4) = *(const f32x4*)&Ot[i * 4];
+      } else {   // row-padded output (facepath.h FP_OPF_OUT_ROWPAD): pixel (y, x) at (y*(OW + 1) + x)*Cout
+        float* ob = p.out + (long)img * p.out_ns;
+        const unsigned q4 = (unsigned)p.Cout >> 2;
+        for (int i = tid; i < n4; i += 256) {
+          const unsigned px = fp_fastdiv((unsigned)i, p.q4_div), cq = (unsigned)i - px * q4;
+          const unsigned m = (unsigned)m_lo + px, oy = fp_fastdiv(m, p.ow_div);
+          *(f32x4*)(ob + (long)(m + oy) * p.Cout + cq * 4) = *(const f32x4*)&Ot[i * 4];
+        }
+      }
     }
     __syncthreads();   // next image visible; Ot free
     tile = next;
@@ -215,7 +227,9 @@ static void stem_geometry(const fp_op& op, int* Wp, int* rows_max) {
 // shape conditions shared by the fp32-image and the u8-frame forms
 static bool stem_shape_ok(const fp_op& op, int table_entries) {
   if (op.KH != op.KW || (op.KH != 3 && op.KH != 5) || op.stride != 2) return false;
-  if (op.out_cmul != 1 || op.out_ld != op.Cout || op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return false;
+  if (op.out_cmul != 1 || op.out_ld != op.Cout) return false;
+  if (!(op.flags & FP_OPF_OUT_ROWPAD) && op.out_ns != (int64_t)op.OH * op.OW * op.Cout) return false;
+  if ((op.flags & FP_OPF_OUT_ROWPAD) && (op.Cout < 8 || op.OW < 2)) return false;   // fp_make_divisor needs d >= 2
   if (op.Cout % 4 || op.Cout <= 0 || op.Cout > 64 || op.out_off % 4 || op.w_off % 4) return false;
   if (op.res_mode != FP_RES_NONE) return false;
   if (op.act != FP_ACT_NONE && op.act != FP_ACT_RELU && op.act != FP_ACT_PRELU) return false;
@@ -234,7 +248,9 @@ static bool stem_shape_ok(const fp_op& op, int table_entries) {
 bool fp_stem_eligible(const fp_op& op) {
   if (op.kind != FP_OP_CONV) return false;
   if (op.Cin != 4 || op.in_ld != 4 || op.in_ns != (int64_t)op.H * op.W * 4 || op.in_off % 4) return false;
-  if ((long)op.N * op.OH * op.OW < 1024L * TMS) return false;     // small batches: one tile per workgroup is fine
+  // small batches: one tile per workgroup (conv_igemm_kernel) is fine -- unless the output is row-padded, which only
+  // this kernel writes
+  if (!(op.flags & FP_OPF_OUT_ROWPAD) && (long)op.N * op.OH * op.OW < 1024L * TMS) return false;
   return stem_shape_ok(op, 0);
 }
 
@@ -253,6 +269,10 @@ static void stem_fill(const fp_op& op, const float* weights, float* arena, StemA
   a.tiles_per_img = fp_ceil_div(a.OHW, TMS);
   a.ntiles = op.N * a.tiles_per_img;
   a.in_ns = op.in_ns;
+  a.out_rowpad = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
+  a.out_ns = op.out_ns;
+  a.q4_div = fp_make_divisor((unsigned)(op.Cout >= 8 ? op.Cout / 4 : 2));
+  a.ow_div = fp_make_divisor((unsigned)(op.OW >= 2 ? op.OW : 2));
   a.frames = nullptr; a.tabs = nullptr; a.lut = nullptr;
   a.frame_bytes = a.row_bytes = 0;
 }

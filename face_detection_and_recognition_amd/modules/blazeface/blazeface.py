@@ -30,8 +30,23 @@ class BlazeBlock(_NoCompute):
             ConvParams(in_channels, out_channels, 1, 1, 0, bias=True))
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
+    ROWPAD = True  # class-wide switch: False keeps every activation dense (A/B parity tests)
 
-    def emit(self, pb, x):
+    def fused(self, pb, x):
+        """True if emit() takes the fused FP_OP_BLAZEBLOCK path for input view x."""
+        OW = x.W // 2 if self.stride == 2 else x.W
+        return (BlazeBlock.FUSE and self.kernel_size == 3 and x.coff == 0 and OW % 4 == 0 and
+                pb.blazeblock_lds_bytes(x.C, cpad(self.out_channels)) <= 80 * 1024)
+
+    def wants_rowpad_input(self, H, W):
+        """True if this block, fed an H x W map, runs on the wave-private kernel that reads a row-padded input
+        (csrc/blaze.hip fp_blazeblock_wp_eligible: stride 1, 24 -> 24, rows of whole 32-pixel tiles)."""
+        return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and self.kernel_size == 3 and self.stride == 1 and
+                self.in_channels == 24 and self.out_channels == 24 and W % 32 == 0 and W >= 64 and H % 4 == 0 and H >= 8)
+
+    def emit(self, pb, x, out_rowpad=False):
+        """out_rowpad: write the output in the row-padded layout (the next block asked for it); only the fused path
+        can."""
         dw, pw = self.convs[0], self.convs[1]
         if self.stride == 2:
             # h = F.pad(x, (0, 2, 0, 2)); dw stride 2, padding 0 (blazeface.py:38-39)
@@ -40,11 +55,11 @@ class BlazeBlock(_NoCompute):
         else:
             OH, OW, pad = x.H, x.W, (1, 1)
             res_mode = L.RES_ADD_BEFORE_ACT
-        if (BlazeBlock.FUSE and self.kernel_size == 3 and x.coff == 0 and OW % 4 == 0 and
-                pb.blazeblock_lds_bytes(x.C, cpad(self.out_channels)) <= 80 * 1024):
-            y = pb.new_buf(OH, OW, self.out_channels)
+        if self.fused(pb, x):
+            y = (pb.new_buf_rowpad if out_rowpad else pb.new_buf)(OH, OW, self.out_channels)
             pb.blazeblock(x, npy(dw.weight), npy(dw.bias), npy(pw.weight), npy(pw.bias), y.view(), self.stride)
             return y
+        assert not out_rowpad and not x.buf.rowpad
         t = pb.new_buf(OH, OW, self.in_channels)
         pb.dwconv(x, npy(dw.weight), t.view(), stride=self.stride, pad=pad, bias=npy(dw.bias))
         y = pb.new_buf(OH, OW, self.out_channels)
@@ -180,15 +195,27 @@ class BlazeFace(nn.Module):
         inp = pb.new_buf(H, W, 3) if frame_hw is None else None      # NHWC, channel-padded to 4
         seq = list(self.backbone) if self.back_model else list(self.backbone1)
         stem = seq[0]
+        # A tensor is kept in the row-padded layout (include/facepath.h) when its consumer is a 24 -> 24 stride-1 block
+        # on a map of whole 32-pixel rows (the wave-private kernel) and its producer can write it (the stem kernel, a
+        # fused block).
+        blocks = seq[2:]
+
+        def rowpad_for(i, h, w):   # should the input of blocks[i] (an h x w map) be row-padded?
+            return i < len(blocks) and isinstance(blocks[i], BlazeBlock) and blocks[i].wants_rowpad_input(h, w)
+
         # F.pad(x, (1, 2, 1, 2)) + 5x5 stride-2 conv + ReLU (blazeface.py:118-120,195)
-        x = pb.new_buf(H // 2, W // 2, 24)
+        x = (pb.new_buf_rowpad if rowpad_for(0, H // 2, W // 2) else pb.new_buf)(H // 2, W // 2, 24)
         if frame_hw is None:
             pb.conv(inp.view(), npy(stem.weight), x.view(), stride=2, pad=(1, 1), bias=npy(stem.bias), act=L.ACT_RELU)
         else:
             pb.stem_u8((H, W, frame_hw[0], frame_hw[1], 0), npy(stem.weight), x.view(), pad=(1, 1), bias=npy(stem.bias),
                        act=L.ACT_RELU)
-        for blk in seq[2:]:
-            y = blk.emit(pb, x.view())
+        for i, blk in enumerate(blocks):
+            if isinstance(blk, BlazeBlock):
+                oh, ow = (x.H // 2, x.W // 2) if blk.stride == 2 else (x.H, x.W)
+                y = blk.emit(pb, x.view(), out_rowpad=blk.fused(pb, x.view()) and rowpad_for(i + 1, oh, ow))
+            else:
+                y = blk.emit(pb, x.view())
             pb.free(x)
             x = y
         if self.back_model:

@@ -34,6 +34,7 @@ class Buf:
     off: int
     size: int    # floats, whole batch
     ns_: int = -1   # per-image stride override (e.g. a head writing into a [B, 896, 16] tensor)
+    rowpad: bool = False   # row-padded layout (include/facepath.h): off = pixel (0, 0) of image 0, row pitch (W+1)*C
 
     @property
     def ld(self):
@@ -148,6 +149,12 @@ class PlanBuilder:
         self.arena = Arena()
         self.peak = 0
         self.alg_bytes = []   # op-granular algorithmic bytes per op, from LOGICAL channel counts
+        self.rowpad_free = {}   # (H, W, C) -> row-padded buffers released by free()
+        self.rowpad_bufs = []   # every row-padded buffer (offsets relative to the row-padded region until finish())
+        self.rowpad_top = 0
+        self.rowpad_end = 0
+        self.has_rowpad = False
+        self._placed = False
 
     # ---- memory ----
     def new_buf(self, H, W, C):
@@ -155,6 +162,27 @@ class PlanBuilder:
         off, size = self.arena.alloc(self.N * H * W * C)
         self.peak = max(self.peak, self.arena.top)
         return Buf(H, W, C, off, size)
+
+    def new_buf_rowpad(self, H, W, C):
+        """A buffer in the row-padded layout of include/facepath.h (one zero pixel after every row, a zero row above and
+        below every image): 3x3 windows read it without bounds checks.  The pads must stay zero for the life of the
+        plan, so these buffers live in a region of their own behind the recycled arena (no op ever writes there except
+        through a row-padded view: a recycled block would carry another tensor's data into the pads), free() keeps
+        them for the next row-padded buffer of the same shape, and the arena of such a plan starts zeroed.  Offsets are
+        relative to that region until finish() places it."""
+        assert not self._placed, "plan already finished"
+        C = cpad(C)
+        pool = self.rowpad_free.setdefault((H, W, C), [])
+        if pool:
+            return pool.pop()
+        ns = ((H + 2) * (W + 1) + 1) * C
+        base = self.rowpad_top
+        self.rowpad_end = base + self.N * ns           # exact end of the region (the arena size is exact too)
+        self.rowpad_top += round_up(self.N * ns, 64)
+        self.has_rowpad = True
+        buf = Buf(H, W, C, base + (W + 2) * C, self.N * ns, ns_=ns, rowpad=True)
+        self.rowpad_bufs.append(buf)
+        return buf
 
     def new_raw(self, floats_per_image):
         """An untyped per-image region (heads / decoded tensors); returns (offset, size) in floats."""
@@ -168,7 +196,10 @@ class PlanBuilder:
         return Buf(H, W, 0, 0, 0)
 
     def free(self, buf):
-        self.arena.release(buf.off, buf.size)
+        if buf.rowpad:
+            self.rowpad_free.setdefault((buf.H, buf.W, buf.C), []).append(buf)
+        else:
+            self.arena.release(buf.off, buf.size)
 
     def add_weight(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
@@ -200,6 +231,10 @@ class PlanBuilder:
         op.w_off = op.scale_off = op.bias_off = op.slope_off = -1
         assert x.cmul == 1, "inputs must be dense channel slices"
         assert out.H == OH and out.W == OW, (out.H, out.W, OH, OW)
+        for v, bit in ((x, L.OPF_IN_ROWPAD), (out, L.OPF_OUT_ROWPAD)):
+            if v.buf.rowpad:
+                assert v.coff == 0 and v.C == v.buf.C and v.cmul == 1, "row-padded buffers are used whole"
+                op.flags |= bit
         return op
 
     def conv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None,
@@ -336,6 +371,8 @@ class PlanBuilder:
         op.kind, op.N, op.H, op.W, op.OH, op.OW = L.OP_STEM_U8, self.N, H, W, out.H, out.W
         op.Cin, op.in_ld, op.in_ns, op.in_off = 3, 3, fh * fw * 3, ext_index
         op.Cout, op.out_ld, op.out_ns, op.out_off, op.out_cmul = out.C, out.buf.ld, out.buf.ns, out.buf.off, 1
+        if out.buf.rowpad:
+            op.flags |= L.OPF_OUT_ROWPAD
         op.KH = op.KW = kh
         op.stride = 2
         op.pad_t, op.pad_l = pad
@@ -435,6 +472,18 @@ class PlanBuilder:
         return out
 
     def finish(self):
+        if not self._placed:   # the row-padded region goes behind the recycled arena: relocate its views once
+            self._placed = True
+            if self.rowpad_top:
+                shift = round_up(self.peak, 64)
+                for op in self.ops:
+                    if op.flags & L.OPF_IN_ROWPAD:
+                        op.in_off += shift
+                    if op.flags & L.OPF_OUT_ROWPAD:
+                        op.out_off += shift
+                for buf in self.rowpad_bufs:
+                    buf.off += shift
+                self.peak = shift + self.rowpad_end
         weights = np.concatenate(self.wchunks) if self.wchunks else np.zeros(4, np.float32)
         return self.ops, weights, self.peak
 
@@ -502,13 +551,17 @@ class CompiledPlan:
         self.weights = cache.device_weights(weights, self.device) if cache is not None else \
             torch.from_numpy(weights).to(self.device)
         self.arena_floats = int(arena_floats)
-        self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=self.device)
+        # row-padded buffers rely on pads that nobody ever writes: start from zeros
+        alloc = torch.zeros if getattr(builder, "has_rowpad", False) else torch.empty
+        self.arena = alloc(self.arena_floats, dtype=torch.float32, device=self.device)
         self.lib = L.load()
         L.check(self.lib.fp_plan_validate(self.ops, self.n_ops, self.weights.numel(), self.arena_floats),
                 "fp_plan_validate")
 
     def buf_tensor(self, buf, N):
         """A torch view [N, H, W, C] of an arena buffer (no copy)."""
+        if buf.rowpad:
+            return self.arena.as_strided((N, buf.H, buf.W, buf.C), (buf.ns, (buf.W + 1) * buf.C, buf.C, 1), buf.off)
         return self.arena[buf.off: buf.off + N * buf.ns].view(N, buf.H, buf.W, buf.C)
 
     _timing = None   # (timer, mask) set by bench.py around a timed step; None = plain fp_plan_run

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 2
+#define FP_ABI_VERSION 3
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -104,8 +104,24 @@ typedef struct fp_op {
   int64_t in_off, out_off, res_off;
   int64_t w_off, scale_off, bias_off, slope_off;
   int32_t act2;                    /* fused ops: activation of the SECOND conv's output (DWPW: FP_ACT_NONE / FP_ACT_SILU) */
-  int32_t reserved;                /* 0 */
+  int32_t flags;                   /* FP_OPF_* bits (0 for dense tensors) */
 } fp_op;
+
+/*
+ * Row-padded activation layout (ABI 3).  A tensor in this layout keeps one ZERO pixel after every image row, one zero
+ * row above and one below every image, and one zero pixel in front of the first pad row:
+ *     pixel (y, x) of image n  at  off + n*ns + (y*(W + 1) + x)*ld          y in [-1, H], x in [-1, W]
+ * (x = -1 is the pad pixel of the row above, so a 3x3 window never needs a bounds check), with
+ * ns >= ((H + 2)*(W + 1) + 1)*ld and off - (W + 2)*ld >= 0 the first float of image 0.  Producers write only
+ * y in [0, H), x in [0, W); whoever owns the arena zeroes the pads once (plan.py allocates such buffers from a region
+ * it never recycles).  The depthwise taps of the BlazeBlocks (blazeface.py:12-47) read it without clamps or masks.
+ *   FP_OPF_IN_ROWPAD  : the input view is row-padded.  FP_OP_BLAZEBLOCK, stride 1, 24 -> 24, OW % 32 == 0, OW >= 64, OH % 4 == 0, OH >= 8
+ *                       (blazeblock_wp_kernel); anything else fails with FP_ERR_UNSUPPORTED.
+ *   FP_OPF_OUT_ROWPAD : the output view is row-padded.  FP_OP_BLAZEBLOCK on its persistent / wave-private kernels,
+ *                       FP_OP_CONV on the stem kernel and FP_OP_STEM_U8.
+ */
+#define FP_OPF_IN_ROWPAD 1
+#define FP_OPF_OUT_ROWPAD 2
 
 /*
  * Weight blob layouts (packed by the host side, see

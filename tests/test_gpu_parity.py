@@ -118,6 +118,79 @@ def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw):
     np.testing.assert_array_equal(outs[True][1], outs[False][1])
 
 
+@pytest.mark.parametrize("back,n", [(True, 2), (True, 19), (False, 5), (True, 40)])
+def test_blazeface_row_padded_chain_matches_dense(dev, back, n):
+    """The 24 -> 24 stride-1 blocks on the wave-private kernel (csrc/blaze.hip blazeblock_wp_kernel, row-padded
+    activations: include/facepath.h FP_OPF_*) against the same network with dense activations: the stem and the
+    stride-2 block write the padded layout (per-tile kernel at n = 2, persistent kernel at n >= 16 on the 128 x 128
+    map), the last block of a chain writes dense again.  Same taps, same k order: the outputs agree to fp32 rounding
+    of one reassociated sum at most."""
+    rng = np.random.default_rng(n)
+    S = 256 if back else 128
+    x = torch.from_numpy(rng.integers(0, 256, (n, S, S, 3), dtype=np.uint8)).to(dev)
+    outs = {}
+    for flag in (True, False):
+        BlazeBlock.ROWPAD = flag
+        try:
+            net = BlazeFace(back)
+            net.load_state_dict(synth_state_dict(net.state_dict(), 7, residual_gain=0.5))
+            net = net.to(dev)
+            plan = net.plan_for(n)
+            names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+            assert any(nm.startswith("blazeblock_wp_kernel") for nm in names) == flag
+            r, c = net.raw_from_u8_nhwc(x)
+            torch.cuda.synchronize()
+            outs[flag] = (r.cpu().numpy().copy(), c.cpu().numpy().copy())
+        finally:
+            BlazeBlock.ROWPAD = True
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-6
+    assert rel_err(outs[True][1], outs[False][1]) < 2e-6
+    # a second run on the same plan: the pads are still zero (nobody writes them)
+    r2, _ = net.raw_from_u8_nhwc(x)
+    assert rel_err(r2.cpu().numpy(), outs[False][0]) < 2e-6
+
+
+@pytest.mark.parametrize("stride,in_rp,out_rp,n,hw", [
+    (1, True, True, 3, (64, 64)),      # wave-private kernel, row-padded -> row-padded
+    (1, True, False, 3, (64, 96)),     # ... -> dense (last block of a chain), 3 strips
+    (1, True, True, 5, (8, 128)),      # two bands only, 4 strips
+    (2, False, True, 3, (128, 128)),   # stride-2 block writes the padded layout: per-tile kernel
+    (2, False, True, 40, (128, 128)),  # ... persistent kernel (>= 2048 tiles)
+    (1, False, True, 3, (64, 64)),     # dense -> row-padded on the stride-1 per-tile kernel
+])
+def test_blazeblock_row_padded_layouts_vs_oracle(dev, stride, in_rp, out_rp, n, hw):
+    """One 24 -> 24 BlazeBlock with its input and / or output in the row-padded layout (include/facepath.h FP_OPF_*)
+    against the CPU oracle (blazeface.py:12-47), and the pads of the output buffer still zero afterwards."""
+    rng = np.random.default_rng(n + stride)
+    H, W = hw
+    blk = BlazeBlock(24, 24, stride=stride)
+    sd = synth_state_dict(blk.state_dict(), 77 + stride)
+    blk.load_state_dict(sd)
+    x = rng.normal(0, 1, (n, 24, H, W)).astype(np.float32)
+    pb = PlanBuilder(n)
+    inp = (pb.new_buf_rowpad if in_rp else pb.new_buf)(H, W, 24)
+    y = blk.emit(pb, inp.view(), out_rowpad=out_rp)
+    assert y.rowpad == out_rp
+    plan = CompiledPlan(pb, dev)
+    name = plan.kernel_name(0)
+    assert name.startswith("blazeblock_wp_kernel") == in_rp, name
+    plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    for _ in range(2):
+        plan.run()
+    torch.cuda.synchronize()
+    got = plan.buf_tensor(y, n).permute(0, 3, 1, 2).cpu().numpy()
+    ref = blazeface_ref._blaze_block(dict(sd), "", torch.from_numpy(x), stride).numpy()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-5
+    if out_rp:   # everything in the output region that is not an interior pixel is still zero
+        OH, OW = y.H, y.W
+        base = y.off - (OW + 2) * y.C
+        region = plan.arena[base: base + n * y.ns].clone()
+        plan.buf_tensor(y, n).zero_()
+        left = plan.arena[base: base + n * y.ns]
+        assert float(region.abs().sum()) > 0 and float(left.abs().max()) == 0.0
+
+
 def test_blazeblock_fused_ragged_tail(dev):
     """M = N*OH*OW not a multiple of the 128-row tile, odd batch: the tail tile must not write out of range."""
     rng = np.random.default_rng(12)

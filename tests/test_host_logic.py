@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_struct_layout_matches_header():
-    # 22 int32 + 10 int64 + 2 int32 (act2, reserved) = 176 bytes; fp_resize_item = 9 int32; fp_ext = pointer + size_t
+    # 22 int32 + 10 int64 + 2 int32 (act2, flags) = 176 bytes; fp_resize_item = 9 int32; fp_ext = pointer + size_t
     assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8 + 2 * 4
     assert ctypes.sizeof(L.FpExt) == 16
     assert ctypes.sizeof(L.FpResizeItem) == 36
@@ -49,6 +49,34 @@ def test_plans_validate_and_reject_bad_offsets(lib):
         bad[0].N = 0
         assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
     assert lib.fp_plan_validate(None, 0, 0, 0) == -1
+
+
+def test_row_padded_views_in_the_blazeface_plan(lib):
+    """include/facepath.h FP_OPF_*: the back model keeps the tensors between its 24 -> 24 stride-1 blocks row-padded;
+    the validator rejects the flags on ops that cannot honour them and views whose pads would leave the arena."""
+    pb = BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0]
+    ops, weights, arena = pb.finish()
+    flags = [op.flags for op in ops[:17]]
+    assert flags[0] == L.OPF_OUT_ROWPAD and flags[1] == L.OPF_IN_ROWPAD | L.OPF_OUT_ROWPAD
+    assert flags[7] == L.OPF_IN_ROWPAD and flags[8] == L.OPF_OUT_ROWPAD and flags[16] == 0
+    names = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops[:17]]
+    assert sum(n.startswith("blazeblock_wp_kernel") for n in names) == 14
+    arr = (L.FpOp * len(ops))(*ops)
+    assert lib.fp_plan_validate(arr, len(ops), weights.size, arena) == 0
+    # row-padded buffers sit behind the recycled arena and never share floats with a dense view
+    lo = min(b.off - (b.W + 2) * b.C for b in pb.rowpad_bufs)
+    for op in ops:
+        if not op.flags & L.OPF_IN_ROWPAD and op.kind not in (L.OP_STEM_U8,):
+            assert op.in_off + (op.N - 1) * op.in_ns + (op.H * op.W - 1) * op.in_ld + op.Cin <= lo
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[16].flags = L.OPF_IN_ROWPAD                # a 24 -> 48 stride-2 block cannot read the padded layout
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[1].in_off = 8                              # the pad row above image 0 would start before the arena
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[1].flags = 4                               # unknown flag bit
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
 
 
 def test_null_and_size_argument_checks(lib):
