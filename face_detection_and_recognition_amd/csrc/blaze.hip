@@ -657,6 +657,8 @@ bool fp_blazeblock_wp_eligible(const fp_op& op) {
 }
 
 static int launch_blazeblock_wp(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  // R = 8 (7.5 instead of 9 window loads per row) measured the same within noise on 128 x 128 maps and 6 % faster on
+  // 64 x 64 ones, against twice the code: R = 4 everywhere
   constexpr int C = 24, R = 4;
   BlazeWpArgs a;
   a.in = arena + op.in_off;
