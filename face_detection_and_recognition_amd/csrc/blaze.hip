@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
           const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * p.Cin + c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            acc[q] += x[q] * w0 + x[q + 1] * w1 + x[q + 2] * w2;
+            acc[q] += x[q] * w0;
+            acc[q] += x[q + 1] * w1;
+            acc[q] += x[q + 2] * w2;
             if (ky == 1) sc[q] = x[q + 1];  // centre tap = x itself
           }
         }
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
           const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * p.Cin + c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            acc[q] += x[2 * q] * w0 + x[2 * q + 1] * w1 + x[2 * q + 2] * w2;
+            acc[q] += x[2 * q] * w0;
+            acc[q] += x[2 * q + 1] * w1;
+            acc[q] += x[2 * q + 2] * w2;
             if (ky < 2) {  // rows 0,1 x cols 2q,2q+1 are the 2x2 max-pool window (always inside the map)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
 
   // XCD-aware order: block b runs on XCD b % 8; each XCD gets a contiguous range of every round's tiles, so the bands
   // above and below a tile (its halo rows) are fetched into the same L2
-  const int G = gridDim.x, GW = G * 4;
+  const int G = gridDim.x;
   int pos;
   {
     const int b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
@@ -514,20 +518,27 @@ __global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
   // byte offsets from p.in / p.out, all scalar: window origin (y0 - 1, x0 - 1) and first output pixel of a tile
   const char* inb = (const char*)p.in;
   char* outb = (char*)p.out;
+  // tile index = (image * strips + strip) * bands + band: a wave's consecutive tiles walk DOWN a strip, so the two halo
+  // rows a band shares with the one above were read by this very wave a few microseconds ago (L1 / L2 hits instead of
+  // the 34 % extra HBM fetch that interleaved tiles cost: profiles/r02_bench_pmc_traffic.json history)
   auto locate = [&](int t, long& ip, long& op) {
-    const unsigned bg = fp_fastdiv((unsigned)t, p.strips_div), sx = (unsigned)t - bg * (unsigned)p.strips;
-    const unsigned img = fp_fastdiv(bg, p.bands_div), y0 = (bg - img * (unsigned)p.bands) * R;
+    const unsigned q = fp_fastdiv((unsigned)t, p.bands_div), y0 = ((unsigned)t - q * (unsigned)p.bands) * R;
+    const unsigned img = fp_fastdiv(q, p.strips_div), sx = q - img * (unsigned)p.strips;
     ip = fp_uniform(((long)img * p.in_ns + ((long)y0 - 1) * p.in_rp + ((long)sx * 32 - 1) * C) * 4);
     op = fp_uniform(((long)img * p.out_ns + (long)y0 * p.out_rp + (long)sx * 32 * C) * 4);
   };
   f32x4 x[3][6];                                           // ring of three input rows
   const long in_rb = (long)p.in_rp * 4, out_rb = (long)p.out_rp * 4;
 
-  int t = pos * 4 + wv;
+  // this wave's contiguous run [t, t_end) of tiles: equal shares, the first (ntiles mod waves) waves take one more
+  const int wi = pos * 4 + wv, nw = G * 4;
+  const int share = p.ntiles / nw, extra = p.ntiles - share * nw;
+  int t = wi * share + min(wi, extra);
+  const int t_end = t + share + (wi < extra ? 1 : 0);
   long in_px = 0;               // byte offset of the current tile's window origin
   long out_px = 0;              // ... of its first output pixel
   long st_px = 0;               // ... of the row waiting in Ot
-  if (t < p.ntiles) {
+  if (t < t_end) {
     locate(t, in_px, out_px);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -537,10 +548,10 @@ __global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
     }
   }
   bool have_prev = false;
-  while (t < p.ntiles) {
-    const int tn = t + GW;
+  while (t < t_end) {
+    const int tn = t + 1;
     long in_nx = 0, out_nx = 0;
-    if (tn < p.ntiles) locate(tn, in_nx, out_nx);
+    if (tn < t_end) locate(tn, in_nx, out_nx);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s0 = r % 3, s1 = (r + 1) % 3, s2 = (r + 2) % 3;   // ring slots of rows y - 1, y, y + 1 (static: unrolled)
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
         const char* rowp = inb + fp_uniform(in_px + (r + 3) * in_rb);
 #pragma unroll
         for (int j = 0; j < 6; ++j) x[s0][j] = *(const f32x4*)(rowp + voff_in + j * C * 4);
-      } else if (tn < p.ntiles) {       // last row of the band: the next tile's first three rows
+      } else if (tn < t_end) {          // last row of the band: the next tile's first three rows
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const char* rowp = inb + fp_uniform(in_nx + ky * in_rb);
@@ -677,13 +688,9 @@ static int launch_blazeblock_wp(const fp_op& op, const float* weights, float* ar
   a.strips_div = fp_make_divisor((unsigned)a.strips);
   a.bands_div = fp_make_divisor((unsigned)a.bands);
   const size_t lds = 4 * ((size_t)10 * C + 32 + 4 * (size_t)(2 * 32 * (C + 4) + 32 * C));
-  // persistent grid: at most 3 workgroups per CU, and no more than gives every wave the same number of tiles when
-  // the tile count allows it (a wave with one tile more than the others sets the kernel's length)
-  int G = fp_ceil_div(a.ntiles, 4);
-  if (G > 256 * 3) {
-    const int per_wave = fp_ceil_div(a.ntiles, 256 * 3 * 4);
-    G = fp_ceil_div(a.ntiles, 4 * per_wave);
-  }
+  // persistent grid: 3 workgroups per CU; every wave owns a contiguous run of tiles (+-1), at least two when there are few
+  int G = fp_ceil_div(a.ntiles, 8);
+  if (G > 256 * 3) G = 256 * 3;
   hipLaunchKernelGGL((blazeblock_wp_kernel<C, R>), dim3(G), dim3(256), lds, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;

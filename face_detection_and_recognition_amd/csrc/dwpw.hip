@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
         const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * KCH + c];
         const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * KCH + c];
 #pragma unroll
-        for (int q = 0; q < P; ++q) a[q] += x[ky][q * S] * w0 + x[ky][q * S + 1] * w1 + x[ky][q * S + 2] * w2;
+        for (int q = 0; q < P; ++q) {   // three statements: each contracts to one packed FMA on the accumulator
+          a[q] += x[ky][q * S] * w0;
+          a[q] += x[ky][q * S + 1] * w1;
+          a[q] += x[ky][q * S + 2] * w2;
+        }
       }
       const f32x4 sc = *(const f32x4*)&Ws[9 * KCH + c];
       const f32x4 bi = *(const f32x4*)&Ws[10 * KCH + c];
@@ -176,12 +180,16 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwArgs p) {
 #pragma unroll
     for (int kq = 0; kq < KCH / 8; ++kq) {
       const f32x4 av = *(const f32x4*)(arow + kq * 8);
+      f32x4 bv[NB];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const f32x4 bv = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+      for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[nb], 0, 0, 0);
-      }
+      for (int t = 0; t < 4; ++t)   // round-robin over the accumulators (common.h FP_MFMA_ORDER)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nb][t], acc[nb], 0, 0, 0);
+          FP_MFMA_ORDER();
+        }
     }
     __syncthreads();  // At / Bs / Ws are rewritten by the next chunk (or by the epilogue)
   }
@@ -423,7 +431,9 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int wy = (q >> 1) * S + ky, wx = (q & 1) * S;
-          a[q] += x[wy][wx] * w0 + x[wy][wx + 1] * w1 + x[wy][wx + 2] * w2;
+          a[q] += x[wy][wx] * w0;   // three statements: each contracts to one packed FMA on the accumulator
+          a[q] += x[wy][wx + 1] * w1;
+          a[q] += x[wy][wx + 2] * w2;
         }
       }
       const f32x4 dsc = *(const f32x4*)&Ws[9 * Gc + gc];
@@ -461,12 +471,18 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 #pragma unroll
       for (int kq = 0; kq < PKC / 8; ++kq) {
         const f32x4 av = *(const f32x4*)(arow + kq * 8);
+        f32x4 bv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const f32x4 bv = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+        // round-robin over the accumulators: a 32x32x2 f32 MFMA that accumulates into the previous one's result issues
+        // at half rate (common.h FP_MFMA_ORDER)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[nb], 0, 0, 0);
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nb][t], acc[nb], 0, 0, 0);
+            FP_MFMA_ORDER();
+          }
       }
     }
     DWPW_STAMP(4);
