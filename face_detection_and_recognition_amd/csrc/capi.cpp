@@ -47,8 +47,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
   if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD)) return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
-  if (in_rp && !fp_blazeblock_wp_eligible(op)) return FP_ERR_UNSUPPORTED;
-  if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_STEM_U8 || (op.kind == FP_OP_CONV && fp_stem_eligible(op))))
+  if (in_rp && !fp_blazeblock_wp_eligible(op) && !fp_blazeblock_wps_eligible(op)) return FP_ERR_UNSUPPORTED;
+  if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_STEM_U8 || op.kind == FP_OP_COPY ||
+                  (op.kind == FP_OP_CONV && fp_stem_eligible(op))))
     return FP_ERR_UNSUPPORTED;
   if (out_rp && (op.out_cmul != 1 || op.out_ld != Cout)) return FP_ERR_UNSUPPORTED;
   // input extent
@@ -196,7 +197,11 @@ const char* fp_op_kernel_name(const fp_op* op) {
               op->out_off % 4 == 0 && op->in_ns % 4 == 0 && op->out_ns % 4 == 0) ? "copy4_kernel" : "copy_kernel";
     case FP_OP_L2NORM: return "l2norm_kernel";
     case FP_OP_BLAZEBLOCK:
-      if (op->flags & FP_OPF_IN_ROWPAD) return "blazeblock_wp_kernel<24>";
+      if (op->flags & FP_OPF_IN_ROWPAD) {
+        if (fp_blazeblock_wp_eligible(*op)) return "blazeblock_wp_kernel<24, 4>";
+        snprintf(buf, sizeof(buf), "blazeblock_wps_kernel<%d>", op->Cin);
+        return buf;
+      }
       if (fp_round_up(op->Cin, 8) <= 32 && fp_round_up(op->Cout, 32) == 32 &&
           fp_ceil_div((long)op->N * op->OH * op->OW, 128) >= 2048)
         snprintf(buf, sizeof(buf), "blazeblock_persist_kernel<%d, %s>", op->stride, fp_blazeblock_fixed24(*op) ? "24, 24" : "0, 0");

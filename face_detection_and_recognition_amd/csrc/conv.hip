@@ -647,6 +647,7 @@ struct CopyArgs {
   float* out;
   int C, in_ld, out_ld, out_cmul, HW;
   long in_ns, out_ns, total;
+  int W, out_rowpad;   // copy4_kernel: the output is row-padded (facepath.h FP_OPF_OUT_ROWPAD): one more pixel per row
 };
 
 __global__ __launch_bounds__(256) void copy_kernel(CopyArgs p) {
@@ -669,7 +670,8 @@ __global__ __launch_bounds__(256) void copy4_kernel(CopyArgs p) {
   const long m = idx / C4;
   const int img = (int)(m / p.HW);
   const int pix = (int)(m - (long)img * p.HW);
-  *(f32x4*)(p.out + (long)img * p.out_ns + (long)pix * p.out_ld + c4 * 4) =
+  const int opix = p.out_rowpad ? pix + pix / p.W : pix;
+  *(f32x4*)(p.out + (long)img * p.out_ns + (long)opix * p.out_ld + c4 * 4) =
       *(const f32x4*)(p.in + (long)img * p.in_ns + (long)pix * p.in_ld + c4 * 4);
 }
 
@@ -858,6 +860,7 @@ int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s) {
   a.out = arena + op.out_off;
   a.C = op.Cin; a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.out_cmul = op.out_cmul;
   a.HW = op.H * op.W; a.in_ns = op.in_ns; a.out_ns = op.out_ns;
+  a.W = op.W; a.out_rowpad = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
   const bool v4 = op.out_cmul == 1 && op.Cin % 4 == 0 && op.in_ld % 4 == 0 && op.out_ld % 4 == 0 && op.in_off % 4 == 0 &&
                   op.out_off % 4 == 0 && op.in_ns % 4 == 0 && op.out_ns % 4 == 0;
   if (v4) {
@@ -866,6 +869,7 @@ int fp_launch_copy(const fp_op& op, float* arena, hipStream_t s) {
     FP_CHECK_LAUNCH();
     return FP_OK;
   }
+  if (a.out_rowpad) return FP_ERR_UNSUPPORTED;   // the scalar form has no row-padded output
   a.total = (long)op.N * a.HW * a.C;
   hipLaunchKernelGGL(copy_kernel, dim3((unsigned)fp_ceil_div(a.total, 256)), dim3(256), 0, s, a);
   FP_CHECK_LAUNCH();

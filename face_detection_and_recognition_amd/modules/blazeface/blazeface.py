@@ -32,15 +32,26 @@ class BlazeBlock(_NoCompute):
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
     ROWPAD = True  # class-wide switch: False keeps every activation dense (A/B parity tests)
 
+    def wide_ok(self, H, W):
+        """True if this block on an H x W map runs on the small-map wave-private kernel (csrc/blaze.hip
+        fp_blazeblock_wps_eligible: stride 1, 48 -> 48 or 96 -> 96, 16- or 32-pixel-wide maps, row-padded input)."""
+        return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and self.kernel_size == 3 and self.stride == 1 and
+                self.in_channels == self.out_channels and self.in_channels in (48, 96) and W in (16, 32) and
+                (H * W) % 32 == 0 and H * W >= 64)
+
     def fused(self, pb, x):
         """True if emit() takes the fused FP_OP_BLAZEBLOCK path for input view x."""
+        if self.wide_ok(x.H, x.W) and x.coff == 0:
+            return True
         OW = x.W // 2 if self.stride == 2 else x.W
         return (BlazeBlock.FUSE and self.kernel_size == 3 and x.coff == 0 and OW % 4 == 0 and
                 pb.blazeblock_lds_bytes(x.C, cpad(self.out_channels)) <= 80 * 1024)
 
     def wants_rowpad_input(self, H, W):
-        """True if this block, fed an H x W map, runs on the wave-private kernel that reads a row-padded input
-        (csrc/blaze.hip fp_blazeblock_wp_eligible: stride 1, 24 -> 24, rows of whole 32-pixel tiles)."""
+        """True if this block, fed an H x W map, runs on a wave-private kernel that reads a row-padded input
+        (csrc/blaze.hip fp_blazeblock_wp_eligible: stride 1, 24 -> 24, rows of whole 32-pixel tiles; or wide_ok)."""
+        if self.wide_ok(H, W):
+            return True
         return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and self.kernel_size == 3 and self.stride == 1 and
                 self.in_channels == 24 and self.out_channels == 24 and W % 32 == 0 and W >= 64 and H % 4 == 0 and H >= 8)
 
@@ -48,6 +59,17 @@ class BlazeBlock(_NoCompute):
         """out_rowpad: write the output in the row-padded layout (the next block asked for it); only the fused path
         can."""
         dw, pw = self.convs[0], self.convs[1]
+        if self.wide_ok(x.H, x.W) and x.coff == 0:
+            tmp = None
+            if not x.buf.rowpad:   # dense producer (the unfused stride-2 block before a 96-channel stage): one copy
+                tmp = pb.new_buf_rowpad(x.H, x.W, x.C)
+                pb.copy(x, tmp.view())
+                x = tmp.view()
+            y = (pb.new_buf_rowpad if out_rowpad else pb.new_buf)(x.H, x.W, self.out_channels)
+            pb.blazeblock(x, npy(dw.weight), npy(dw.bias), npy(pw.weight), npy(pw.bias), y.view(), 1)
+            if tmp is not None:
+                pb.free(tmp)
+            return y
         if self.stride == 2:
             # h = F.pad(x, (0, 2, 0, 2)); dw stride 2, padding 0 (blazeface.py:38-39)
             OH, OW, pad = x.H // 2, x.W // 2, (0, 0)

@@ -150,30 +150,35 @@ def test_blazeface_row_padded_chain_matches_dense(dev, back, n):
     assert rel_err(r2.cpu().numpy(), outs[False][0]) < 2e-6
 
 
-@pytest.mark.parametrize("stride,in_rp,out_rp,n,hw", [
-    (1, True, True, 3, (64, 64)),      # wave-private kernel, row-padded -> row-padded
-    (1, True, False, 3, (64, 96)),     # ... -> dense (last block of a chain), 3 strips
-    (1, True, True, 5, (8, 128)),      # two bands only, 4 strips
-    (2, False, True, 3, (128, 128)),   # stride-2 block writes the padded layout: per-tile kernel
-    (2, False, True, 40, (128, 128)),  # ... persistent kernel (>= 2048 tiles)
-    (1, False, True, 3, (64, 64)),     # dense -> row-padded on the stride-1 per-tile kernel
+@pytest.mark.parametrize("stride,in_rp,out_rp,n,hw,c", [
+    (1, True, True, 3, (64, 64), 24),      # wave-private kernel, row-padded -> row-padded
+    (1, True, False, 3, (64, 96), 24),     # ... -> dense (last block of a chain), 3 strips
+    (1, True, True, 5, (8, 128), 24),      # two bands only, 4 strips
+    (2, False, True, 3, (128, 128), 24),   # stride-2 block writes the padded layout: per-tile kernel
+    (2, False, True, 40, (128, 128), 24),  # ... persistent kernel (>= 2048 tiles)
+    (1, False, True, 3, (64, 64), 24),     # dense -> row-padded on the stride-1 per-tile kernel
+    (1, True, True, 5, (32, 32), 48),      # small-map kernel: one row per tile
+    (1, True, False, 7, (32, 32), 48),
+    (1, True, True, 5, (16, 16), 96),      # two rows per tile, 4 channel passes
+    (1, True, False, 3, (6, 16), 96),      # three tiles per image
+    (1, False, False, 5, (16, 16), 96),    # dense input: emit() inserts the copy into the padded layout
 ])
-def test_blazeblock_row_padded_layouts_vs_oracle(dev, stride, in_rp, out_rp, n, hw):
-    """One 24 -> 24 BlazeBlock with its input and / or output in the row-padded layout (include/facepath.h FP_OPF_*)
+def test_blazeblock_row_padded_layouts_vs_oracle(dev, stride, in_rp, out_rp, n, hw, c):
+    """One c -> c BlazeBlock with its input and / or output in the row-padded layout (include/facepath.h FP_OPF_*)
     against the CPU oracle (blazeface.py:12-47), and the pads of the output buffer still zero afterwards."""
     rng = np.random.default_rng(n + stride)
     H, W = hw
-    blk = BlazeBlock(24, 24, stride=stride)
+    blk = BlazeBlock(c, c, stride=stride)
     sd = synth_state_dict(blk.state_dict(), 77 + stride)
     blk.load_state_dict(sd)
-    x = rng.normal(0, 1, (n, 24, H, W)).astype(np.float32)
+    x = rng.normal(0, 1, (n, c, H, W)).astype(np.float32)
     pb = PlanBuilder(n)
-    inp = (pb.new_buf_rowpad if in_rp else pb.new_buf)(H, W, 24)
+    inp = (pb.new_buf_rowpad if in_rp else pb.new_buf)(H, W, c)
     y = blk.emit(pb, inp.view(), out_rowpad=out_rp)
     assert y.rowpad == out_rp
     plan = CompiledPlan(pb, dev)
-    name = plan.kernel_name(0)
-    assert name.startswith("blazeblock_wp_kernel") == in_rp, name
+    name = plan.kernel_name(plan.n_ops - 1)
+    assert name.startswith("blazeblock_wp_kernel" if c == 24 else "blazeblock_wps_kernel") == (in_rp or c != 24), name
     plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
     for _ in range(2):
         plan.run()

@@ -56,11 +56,15 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
     the validator rejects the flags on ops that cannot honour them and views whose pads would leave the arena."""
     pb = BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0]
     ops, weights, arena = pb.finish()
-    flags = [op.flags for op in ops[:17]]
+    flags = [op.flags for op in ops]
     assert flags[0] == L.OPF_OUT_ROWPAD and flags[1] == L.OPF_IN_ROWPAD | L.OPF_OUT_ROWPAD
-    assert flags[7] == L.OPF_IN_ROWPAD and flags[8] == L.OPF_OUT_ROWPAD and flags[16] == 0
-    names = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops[:17]]
+    assert flags[7] == L.OPF_IN_ROWPAD and flags[8] == L.OPF_OUT_ROWPAD
+    assert flags[16] == L.OPF_OUT_ROWPAD and flags[23] == L.OPF_IN_ROWPAD     # 24 -> 48 stride 2, last 48 -> 48 block
+    assert flags[24] == 0 and flags[25] == 0 and flags[26] == L.OPF_OUT_ROWPAD  # unfused stride-2 block, then the copy
+    names = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops]
     assert sum(n.startswith("blazeblock_wp_kernel") for n in names) == 14
+    assert sum(n.startswith("blazeblock_wps_kernel<48>") for n in names) == 7
+    assert sum(n.startswith("blazeblock_wps_kernel<96>") for n in names) == 7 and names[26] == "copy4_kernel"
     arr = (L.FpOp * len(ops))(*ops)
     assert lib.fp_plan_validate(arr, len(ops), weights.size, arena) == 0
     # row-padded buffers sit behind the recycled arena and never share floats with a dense view
@@ -69,7 +73,7 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
         if not op.flags & L.OPF_IN_ROWPAD and op.kind not in (L.OP_STEM_U8,):
             assert op.in_off + (op.N - 1) * op.in_ns + (op.H * op.W - 1) * op.in_ld + op.Cin <= lo
     bad = (L.FpOp * len(ops))(*ops)
-    bad[16].flags = L.OPF_IN_ROWPAD                # a 24 -> 48 stride-2 block cannot read the padded layout
+    bad[16].flags |= L.OPF_IN_ROWPAD               # a 24 -> 48 stride-2 block cannot read the padded layout
     assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
     bad = (L.FpOp * len(ops))(*ops)
     bad[1].in_off = 8                              # the pad row above image 0 would start before the arena
