@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
   op.in_off = 0; op.in_ld = G; op.in_ns = (long)HW * HW * G;
   op.out_off = in_elems; op.out_ld = Cout; op.out_ns = (long)OHW * OHW * Cout; op.out_cmul = 1;
   op.res_off = in_elems + out_elems; op.res_ld = Cout; op.res_ns = op.out_ns; op.res_C = Cout;
-  op.w_off = 0; op.slope_off = dw_elems;
+  op.w_off = 0; op.slope_off = dw_elems; op.bias_off = -1; op.scale_off = -1;
   unsigned long long* stamps;
   const size_t ns = 4 * 4 * FP_DWPW_NUNIT * FP_DWPW_NSTAMP;
   hipMalloc(&stamps, ns * 8);
