@@ -478,6 +478,29 @@ def test_plan_runs_on_a_prefix_of_its_capacity(dev):
         big.run(n=41)
 
 
+def test_blazeface_plan_with_row_padded_buffers_runs_on_a_prefix(dev):
+    """A BlazeFace plan of capacity 40 (persistent stride-2 kernel at n = 40, per-tile kernel at n = 3: both write the
+    row-padded layout; the wave-private kernels and the stem follow the actual n) run on 3, then 40, then 17 images
+    gives what plans emitted for those batch sizes give: per-image strides and pads do not depend on the batch."""
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(0, 256, (40, 256, 256, 3), dtype=np.uint8)).to(dev)
+    net = BlazeFace(True)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 11, residual_gain=0.5))
+    net = net.to(dev)
+    big = net.plan_for(40)
+    assert any(big.ops[i].flags for i in range(big.n_ops))
+    lut = torch.from_numpy(image_ref.blaze_lut()).to(dev)
+    for n in (3, 40, 17):
+        big.input[:n, ..., :3].copy_(lut[x[:n].long()])
+        big.run(n=n)
+        got_r, got_c = big.r[:n].clone(), big.c[:n].clone()
+        small = net.plan_for(n)
+        small.input[..., :3].copy_(lut[x[:n].long()])
+        small.run()
+        torch.cuda.synchronize()
+        assert torch.equal(got_r, small.r[:n]) and torch.equal(got_c, small.c[:n])
+
+
 def test_resize_normalize_vs_oracle(dev, lib):
     rng = np.random.default_rng(3)
     frames = rng.integers(0, 256, (3, 72, 128, 3), dtype=np.uint8)
