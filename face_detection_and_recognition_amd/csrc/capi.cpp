@@ -45,7 +45,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
                     op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
-  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD)) return FP_ERR_INVALID_ARG;
+  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3)) return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
+    return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
   if (in_rp && !fp_blazeblock_wp_eligible(op) && !fp_blazeblock_wps_eligible(op)) return FP_ERR_UNSUPPORTED;
   if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_STEM_U8 || op.kind == FP_OP_COPY ||

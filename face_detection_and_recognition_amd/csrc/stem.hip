@@ -30,6 +30,7 @@ struct StemArgs {
   int H, W, OH, OW, OHW, Cout, Npad, Kpad, act, pad_t, pad_l, Wp, rows_max, tiles_per_img, ntiles;
   long in_ns, out_ns;
   int out_rowpad;            // output in the row-padded layout (facepath.h)
+  int c4;                    // the pixel's fourth channel carries weights (0: 3-channel image padded to 16 bytes)
   fp_divisor q4_div, ow_div;
   // U8 input: the H x W image is a letterbox canvas resampled from u8 frames while it is staged (letterbox.h)
   const uint8_t* frames;
@@ -163,7 +164,9 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
       for (int nb = 0; nb < NB; ++nb) {
         const f32x4 bv = *(const f32x4*)&Bs[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc[nb], 0, 0, 0);
+        for (int e = 0; e < 3; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc[nb], 0, 0, 0);
+        // the pad channel of a 3-channel image meets zero weights: its MFMA (a quarter of them) is skipped
+        if (p.c4) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bv[3], acc[nb], 0, 0, 0);
       }
     }
     // epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -270,6 +273,7 @@ static void stem_fill(const fp_op& op, const float* weights, float* arena, StemA
   a.ntiles = op.N * a.tiles_per_img;
   a.in_ns = op.in_ns;
   a.out_rowpad = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
+  a.c4 = (op.kind == FP_OP_STEM_U8 || (op.flags & FP_OPF_IN_C3)) ? 0 : 1;
   a.out_ns = op.out_ns;
   a.q4_div = fp_make_divisor((unsigned)(op.Cout >= 8 ? op.Cout / 4 : 2));
   a.ow_div = fp_make_divisor((unsigned)(op.OW >= 2 ? op.OW : 2));

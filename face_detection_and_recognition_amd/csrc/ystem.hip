@@ -41,6 +41,7 @@ struct YStemArgs {
   const float* bi2;     // [NB2*16]
   int H, W, H1, W1, W2o, C1, C2, a_ld, p_ld, tiles_x, tiles_per_img, ntiles;
   long in_ns, a_ns, p_ns;
+  int c4;               // the pixel's fourth channel carries weights (0: 3-channel image, facepath.h FP_OPF_IN_C3)
   // U8 input (the letterbox fused into the staging, letterbox.h): frames [N][fh][fw][3] u8, tap tables of the H x W canvas
   const uint8_t* frames;
   const fp_lb_tap* xtab;
@@ -151,10 +152,16 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
         const f32x4 a1 = *(const f32x4*)(base1 + (ky * IC + kx) * 4);
         const f32x4 bv = *(const f32x4*)&W1s[((kq * 2 + h) * 32 + lr) * 4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 3; ++e) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bv[e], acc0, 0, 0, 0);
           FP_MFMA_ORDER();
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bv[e], acc1, 0, 0, 0);
+          FP_MFMA_ORDER();
+        }
+        if (p.c4) {   // the pad channel of a 3-channel image meets zero weights: skipped (facepath.h FP_OPF_IN_C3)
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], bv[3], acc0, 0, 0, 0);
+          FP_MFMA_ORDER();
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], bv[3], acc1, 0, 0, 0);
           FP_MFMA_ORDER();
         }
       }
@@ -310,6 +317,7 @@ int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStre
   const int rc = ystem_fill(op, weights, arena, a);
   if (rc != FP_OK) return rc;
   a.in = arena + op.in_off;
+  a.c4 = (op.flags & FP_OPF_IN_C3) ? 0 : 1;
   return ystem_launch<false>(op, a, s);
 }
 
@@ -331,5 +339,6 @@ int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, cons
   a.lut = (const float*)ext[e + 2].ptr;
   a.row_bytes = (long)fw * 3;
   a.frame_bytes = (long)fh * fw * 3;
+  a.c4 = 0;
   return ystem_launch<true>(op, a, s);
 }

@@ -249,6 +249,8 @@ class PlanBuilder:
         op.pad_t, op.pad_l = pad
         op.act, op.res_mode = act, res_mode
         op.w_off = self.add_weight(pack_conv_weight(w, x.C, out.C))
+        if cin == 3 and x.C == 4 and x.buf.ld == 4:   # 3-channel image padded to 16-byte pixels: the pad channel's weights are zero
+            op.flags |= L.OPF_IN_C3
         if scale is not None:
             op.scale_off = self.add_weight(pad_vec(scale, out.C, 0.0))
         if bias is not None:
@@ -401,6 +403,8 @@ class PlanBuilder:
             assert x.C == 4 and x.buf.ld == 4 and x.coff == 0
             H, W = x.H, x.W
             op = self._base(L.OP_YSTEM, x, a_out, H // 2, W // 2)
+            if w1.shape[1] == 3:   # 3-channel image in 16-byte pixels: the pad channel's weights are zero
+                op.flags |= L.OPF_IN_C3
         else:
             # u8 = (H, W, frame_h, frame_w, ext_index): the H x W canvas is never materialised; the op reads the frames
             # (external buffers ext_index .. ext_index + 2: frames, tap tables, LUT) through fp_plan_run_ext

@@ -122,6 +122,13 @@ typedef struct fp_op {
  */
 #define FP_OPF_IN_ROWPAD 1
 #define FP_OPF_OUT_ROWPAD 2
+/*
+ * FP_OPF_IN_C3 : the op reads a 4-float pixel (Cin = in_ld = 4) whose FOURTH channel meets zero weights -- a 3-channel
+ *                image padded to 16 bytes, as every network stem here is.  FP_OP_CONV on the stem kernel and
+ *                FP_OP_YSTEM skip that channel's MFMAs (a quarter of the stem's matrix work); the result is
+ *                unchanged.  The *_U8 ops (Cin = 3) always do.  Only valid with Cin = 4.
+ */
+#define FP_OPF_IN_C3 4
 
 /*
  * Weight blob layouts (packed by the host side, see

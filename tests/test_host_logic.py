@@ -79,8 +79,14 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
     bad[1].in_off = 8                              # the pad row above image 0 would start before the arena
     assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
     bad = (L.FpOp * len(ops))(*ops)
-    bad[1].flags = 4                               # unknown flag bit
+    bad[1].flags = 8                               # unknown flag bit
     assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[1].flags |= L.OPF_IN_C3                    # "fourth channel is padding" only makes sense on a 4-float pixel
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
+    # the fp32-canvas form of the stem is a CONV on 4-float pixels with 3-channel weights: the planner says so
+    pb2 = BlazeFace(True)._emit(4)[0]
+    assert pb2.ops[0].kind == L.OP_CONV and pb2.ops[0].flags & L.OPF_IN_C3 and validate_on_host(pb2) == 0
 
 
 def test_null_and_size_argument_checks(lib):
