@@ -76,6 +76,7 @@ int fp_launch_l2norm(const fp_op& op, float* arena, hipStream_t s);
 int fp_launch_blazeblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_blazeblock_wp_eligible(const fp_op& op);   // row-padded input: the wave-private kernel takes it (24 -> 24)
 bool fp_blazeblock_wps_eligible(const fp_op& op);  // ... its small-map form for the 48- and 96-channel blocks
+int fp_launch_blazeblock_rowpad(const fp_op& op, const float* weights, float* arena, hipStream_t s);   // blazewp.hip
 bool fp_blazeblock_fixed24(const fp_op& op);   // persistent BlazeBlock instantiated with compile-time 24 -> 24 widths
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel, false: dwpw_kernel

@@ -33,7 +33,7 @@ class BlazeBlock(_NoCompute):
     ROWPAD = True  # class-wide switch: False keeps every activation dense (A/B parity tests)
 
     def wide_ok(self, H, W):
-        """True if this block on an H x W map runs on the small-map wave-private kernel (csrc/blaze.hip
+        """True if this block on an H x W map runs on the small-map wave-private kernel (csrc/blazewp.hip
         fp_blazeblock_wps_eligible: stride 1, 48 -> 48 or 96 -> 96, 16- or 32-pixel-wide maps, row-padded input)."""
         return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and self.kernel_size == 3 and self.stride == 1 and
                 self.in_channels == self.out_channels and self.in_channels in (48, 96) and W in (16, 32) and
@@ -49,7 +49,7 @@ class BlazeBlock(_NoCompute):
 
     def wants_rowpad_input(self, H, W):
         """True if this block, fed an H x W map, runs on a wave-private kernel that reads a row-padded input
-        (csrc/blaze.hip fp_blazeblock_wp_eligible: stride 1, 24 -> 24, rows of whole 32-pixel tiles; or wide_ok)."""
+        (csrc/blazewp.hip fp_blazeblock_wp_eligible: stride 1, 24 -> 24, rows of whole 32-pixel tiles; or wide_ok)."""
         if self.wide_ok(H, W):
             return True
         return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and self.kernel_size == 3 and self.stride == 1 and

@@ -120,7 +120,7 @@ def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw):
 
 @pytest.mark.parametrize("back,n", [(True, 2), (True, 19), (False, 5), (True, 40)])
 def test_blazeface_row_padded_chain_matches_dense(dev, back, n):
-    """The 24 -> 24 stride-1 blocks on the wave-private kernel (csrc/blaze.hip blazeblock_wp_kernel, row-padded
+    """The 24 -> 24 stride-1 blocks on the wave-private kernel (csrc/blazewp.hip blazeblock_wp_kernel, row-padded
     activations: include/facepath.h FP_OPF_*) against the same network with dense activations: the stem and the
     stride-2 block write the padded layout (per-tile kernel at n = 2, persistent kernel at n >= 16 on the 128 x 128
     map), the last block of a chain writes dense again.  Same taps, same k order: the outputs agree to fp32 rounding
