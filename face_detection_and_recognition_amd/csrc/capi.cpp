@@ -212,7 +212,8 @@ const char* fp_op_kernel_name(const fp_op* op) {
       return buf;
     case FP_OP_DWPW:
       if (fp_dwpw_persistent(*op)) {
-        snprintf(buf, sizeof(buf), "dwpw_persist_kernel<%d, %d>", (int)fp_round_up(op->Cout, 32) / 32, op->stride);
+        snprintf(buf, sizeof(buf), "%s<%d, %d>", fp_dwpw_wave_private(*op) ? "dwpw_wp_kernel" : "dwpw_persist_kernel",
+                 (int)fp_round_up(op->Cout, 32) / 32, op->stride);
         return buf;
       }
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,

@@ -593,6 +593,253 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wave-private form of the fused depthwise + projection op, for the layers whose WHOLE projection matrix fits LDS
+// (G * Npad * 4 <= 64 KB: every Mobile-FaceNet block on the 56 x 56 and 28 x 28 maps).
+// dwpw_persist_kernel synchronises its four waves twice per (tile, chunk) unit, which keeps them -- and, in practice,
+// the two workgroups of a CU -- in lock step: they run their MFMA phases together (8.6-9.3 k cycles instead of 4.4 k,
+// tools/lab/dwpw_lab) and their VALU phases together (matrix pipe idle): 52 % pipe utilisation.  pws_kernel, whose
+// waves own their tiles end to end and never meet at a barrier, reaches 87 %.  Same idea here: a WAVE owns a tile of 8
+// patches (32 output pixels) for all chunks -- window (one (patch, 4-channel) item per lane, prefetched a unit ahead)
+// -> depthwise + affine + PReLU -> its private A tile in LDS -> MFMAs against the projection weights resident in LDS
+// -> (after the last chunk) epilogue staged in the same private rows -> 16-byte stores.  The only barrier is the one
+// after the weights are staged; the 8 waves of a CU drift apart and fill each other's gaps.
+template <int NB, int S>
+__global__ __launch_bounds__(256, 2) void dwpw_wp_kernel(DwPwArgs p) {
+  constexpr int BN = NB * 32;
+  constexpr int WR = S + 3;   // window rows = window columns
+  constexpr int WV = 32 * PLDT + 32;    // floats per wave region: A tile [32][PLDT], then Mrow[32]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Gc = p.G;
+  float* Ws = smem;                     // [12][G]     taps 0..8, scale, bias, slope (ones without PReLU)
+  float* Osl = Ws + 12 * Gc;            // [BN]        output PReLU slopes (ones without one)
+  float* W2s = Osl + BN;                // [G/4][BN][4] packed projection weights, all chunks
+  float* Wv = W2s + Gc * BN;            // 4 wave regions
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  for (int i = tid; i < 3 * Gc; i += 256) {   // 12*G/4 float4s
+    const int row = (i * 4) / Gc;
+    f32x4 v = {1.f, 1.f, 1.f, 1.f};
+    if (row < 11 || p.has_slope) v = *(const f32x4*)(p.dwp + (long)i * 4);
+    *(f32x4*)&Ws[i * 4] = v;
+  }
+  if (tid < BN) Osl[tid] = (p.oslope && tid < p.Cout) ? p.oslope[tid] : 1.f;
+  for (int i = tid; i < (Gc * BN) / 4; i += 256) *(f32x4*)&W2s[i * 4] = *(const f32x4*)(p.pwp + (long)i * 4);
+
+  float* At = Wv + wave * WV;           // [32][PLDT]  this wave's depthwise output; epilogue staging
+  int* Mrow = (int*)(At + 32 * PLDT);   // [32]        output pixel index of each tile row (-1: past the end)
+
+  // wave-level virtual blocks: wave w of workgroup b is virtual block 4*pos(b) + w of NV = 4 * gridDim.x; a workgroup's
+  // four waves take four consecutive 8-patch tiles (their windows overlap: L1)
+  const int NV = gridDim.x * 4;
+  int vb;
+  {
+    const int G = gridDim.x, b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
+    vb = ((xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k) * 4 + wave;
+  }
+  const int nch = Gc / PKC;
+  const int c = (lane & 7) * 4;     // this lane's 4 channels inside a chunk
+  const int g = lane >> 3;          // this lane's patch inside the tile (0..7)
+  const unsigned PWc = (unsigned)p.OW >> 1, PPI = ((unsigned)p.OH >> 1) * PWc;   // patches per row / per image
+  const unsigned npatch = (unsigned)p.N * PPI;
+  const long ntw = ((long)npatch + 7) / 8;   // 8-patch tiles
+
+  long pk = 0;
+  long ptile = vb;
+  int pch = 0;
+  long rowoff[WR];
+  int coloff[WR];
+  unsigned xmask = 0;                // bit wy*WR+wx: window position inside the image (else zero padding)
+  auto decode = [&](long tile) {
+    unsigned pi = (unsigned)tile * 8u + (unsigned)g;
+    pi = pi < npatch ? pi : npatch - 1;   // tail patches recompute the last one; they are never stored
+    const unsigned img = pi / PPI, rem = pi - img * PPI;
+    const unsigned py = rem / PWc, px = rem - py * PWc;
+    const int iy0 = (int)(2 * py) * S - 1, ix0 = (int)(2 * px) * S - 1;
+    unsigned rowv = 0, colv = 0;
+#pragma unroll
+    for (int w = 0; w < WR; ++w) {
+      const int iy = iy0 + w, ix = ix0 + w;
+      rowoff[w] = (long)img * p.in_ns + c + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+      coloff[w] = min(max(ix, 0), p.W - 1) * p.in_ld;
+      if ((unsigned)iy < (unsigned)p.H) rowv |= 1u << w;
+      if ((unsigned)ix < (unsigned)p.W) colv |= 1u << w;
+    }
+    xmask = 0;
+#pragma unroll
+    for (int w = 0; w < WR; ++w)
+      if ((rowv >> w) & 1u) xmask |= colv << (w * WR);
+  };
+  f32x4 x[WR][WR];
+  auto issue_loads = [&](int ch) {   // raw (clamped-address) window; the padding mask is applied when it is consumed
+    const float* ib = p.in + ch * PKC;
+#pragma unroll
+    for (int wy = 0; wy < WR; ++wy)
+#pragma unroll
+      for (int wx = 0; wx < WR; ++wx) x[wy][wx] = *(const f32x4*)(ib + rowoff[wy] + coloff[wx]);
+  };
+  if (ptile < ntw) {
+    decode(ptile);
+    issue_loads(0);
+  }
+
+  // per-column projection affine (lane constants for the whole kernel)
+  const float* pscale = p.pwp + (long)Gc * p.Npad;
+  const float* pbias = pscale + ((p.Cout + 3) & ~3);
+  float sc[NB], bi[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = nb * 32 + lr;
+    const int nn = n < p.Cout ? n : 0;
+    sc[nb] = pscale[nn];
+    bi[nb] = pbias[nn];
+  }
+  __syncthreads();   // Ws / Osl / W2s staged: the only workgroup barrier
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  long tile = vb;
+  int ch = 0;
+  while (tile < ntw) {
+    if (ch == 0 && lane < 32) {   // output pixel of every tile row, for the epilogue
+      const unsigned pi = (unsigned)tile * 8u + ((unsigned)lane >> 2);
+      int m = -1;
+      if (pi < npatch) {
+        const unsigned img = pi / PPI, rem = pi - img * PPI;
+        const unsigned py = rem / PWc, px = rem - py * PWc;
+        m = (int)(img * (unsigned)p.OHW + (2 * py + ((lane >> 1) & 1)) * (unsigned)p.OW + 2 * px + (lane & 1));
+      }
+      Mrow[lane] = m;
+    }
+    // ---- depthwise + affine + PReLU of this unit from the prefetched window -> A tile ----
+    {
+      const int gc = ch * PKC + c;
+      f32x4 a[4] = {z, z, z, z};
+#pragma unroll
+      for (int wy = 0; wy < WR; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < WR; ++wx) {
+          const bool edge = wy == 0 || wx == 0 || (S == 1 && (wy == WR - 1 || wx == WR - 1));
+          if (edge) x[wy][wx] = ((xmask >> (wy * WR + wx)) & 1u) ? x[wy][wx] : z;
+        }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const f32x4 w0 = *(const f32x4*)&Ws[(ky * 3 + 0) * Gc + gc];
+        const f32x4 w1 = *(const f32x4*)&Ws[(ky * 3 + 1) * Gc + gc];
+        const f32x4 w2 = *(const f32x4*)&Ws[(ky * 3 + 2) * Gc + gc];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int wy = (q >> 1) * S + ky, wx = (q & 1) * S;
+          a[q] += x[wy][wx] * w0;   // three statements: each contracts to one packed FMA on the accumulator
+          a[q] += x[wy][wx + 1] * w1;
+          a[q] += x[wy][wx + 2] * w2;
+        }
+      }
+      const f32x4 dsc = *(const f32x4*)&Ws[9 * Gc + gc];
+      const f32x4 dbi = *(const f32x4*)&Ws[10 * Gc + gc];
+      const f32x4 dsl = *(const f32x4*)&Ws[11 * Gc + gc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = a[q] * dsc + dbi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * dsl[e];
+        *(f32x4*)&At[(g * 4 + q) * PLDT + c] = v;
+      }
+    }
+    // ---- next unit's window (same tile, next chunk -- or the first chunk of this wave's next tile) ----
+    if (++pch == nch) {
+      pch = 0;
+      ptile = ++pk * NV + vb;
+      if (ptile < ntw) decode(ptile);
+    }
+    if (ptile < ntw) issue_loads(pch);
+    // ---- projection MFMAs of this unit ----
+    {
+      const float* arow = &At[lr * PLDT + 4 * h];
+      const float* bch = &W2s[(long)ch * PKC * BN];
+#pragma unroll
+      for (int kq = 0; kq < PKC / 8; ++kq) {
+        const f32x4 av = *(const f32x4*)(arow + kq * 8);
+        f32x4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const f32x4*)&bch[((kq * 2 + h) * BN + nb * 32 + lr) * 4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nb][t], acc[nb], 0, 0, 0);
+            FP_MFMA_ORDER();
+          }
+      }
+    }
+    if (++ch < nch) continue;
+    ch = 0;
+    // ---- epilogue of the tile: acc*scale+bias staged in this wave's own A rows (32 columns per pass), output PReLU or
+    // residual, 16-byte stores ----
+    {
+      const bool full_tile = ((unsigned)tile + 1u) * 8u <= npatch && p.Cout == BN;   // uniform
+      auto epi = [&](auto res_c, auto oact_c, auto full_c) {
+        constexpr bool RES = decltype(res_c)::value, OACT = decltype(oact_c)::value, FULL = decltype(full_c)::value;
+        const int rl0 = lane >> 3, cc = (lane & 7) * 4;   // local rows rl0 + 8*j, 8 float4s per 32-column row
+        f32x4 rr[4], v[4];
+        auto load_res = [&](int nb) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = Mrow[rl0 + 8 * j], n = nb * 32 + cc;
+            const bool ok = FULL || (m >= 0 && n < p.Cout);
+            rr[j] = ok ? *(const f32x4*)(p.res + (long)m * p.res_ld + n) : z;
+          }
+        };
+        if (RES) load_res(0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            At[row * PLDT + lr] = acc[nb][reg] * sc[nb] + bi[nb];
+            acc[nb][reg] = 0.f;
+          }
+          f32x4 osl = {1.f, 1.f, 1.f, 1.f};
+          if (OACT) osl = *(const f32x4*)&Osl[nb * 32 + cc];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = *(const f32x4*)&At[(rl0 + 8 * j) * PLDT + cc];
+            if (OACT) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * osl[e];
+            }
+            if (RES) v[j] += rr[j];
+          }
+          if (RES && nb + 1 < NB) load_res(nb + 1);   // before this pass's stores: vmcnt is one in-order queue
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = Mrow[rl0 + 8 * j], n = nb * 32 + cc;
+            if (FULL || (m >= 0 && n < p.Cout)) *(f32x4*)(p.out + (long)m * p.out_ld + n) = v[j];
+          }
+        }
+      };
+      if (full_tile) {
+        if (p.oslope) epi(std::false_type{}, std::true_type{}, std::true_type{});   // the planner never combines the two
+        else if (p.has_res) epi(std::true_type{}, std::false_type{}, std::true_type{});
+        else epi(std::false_type{}, std::false_type{}, std::true_type{});
+      } else {
+        if (p.oslope) epi(std::false_type{}, std::true_type{}, std::false_type{});
+        else if (p.has_res) epi(std::true_type{}, std::false_type{}, std::false_type{});
+        else epi(std::false_type{}, std::false_type{}, std::false_type{});
+      }
+    }
+    tile += NV;
+  }
+}
+
 }  // namespace
 
 static size_t dwpw_persist_lds(int NB, int G) {
@@ -612,6 +859,12 @@ bool fp_dwpw_persistent(const fp_op& op) {
 #endif
   if ((long)op.N * op.OH * op.OW < FP_DWPW_PERSIST_MIN_TILES * TM) return false;
   return dwpw_persist_lds(NB, op.Cin) <= 80 * 1024;
+}
+
+// The persistent shapes whose whole packed projection matrix (G x Npad floats) fits 64 KB of LDS take the wave-private
+// kernel: every Mobile-FaceNet block on the 56 x 56 and 28 x 28 maps (the 14 x 14 blocks have 128 KB of it).
+bool fp_dwpw_wave_private(const fp_op& op) {
+  return fp_dwpw_persistent(op) && (size_t)op.Cin * fp_round_up(op.Cout, 32) * 4 <= 64 * 1024;
 }
 
 #ifdef FP_DWPW_STAMPS
@@ -674,6 +927,23 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                         \
     hipLaunchKernelGGL((dwpw_persist_kernel<NBV, SV>), dim3(nblk), dim3(256), plds, s, b);                      \
   } while (0)
+      if (fp_dwpw_wave_private(op)) {   // whole projection matrix resident in LDS: the wave-private kernel
+        const size_t wlds = 4 * ((size_t)12 * a.G + (size_t)NB * 32 + (size_t)a.G * NB * 32 + 4 * (size_t)(32 * PLDT + 32));
+        const long ntw = ((long)op.N * (op.OH / 2) * (op.OW / 2) + 7) / 8;
+        int nwg = 512;
+        if ((long)nwg * 4 > ntw) nwg = (int)((ntw + 3) / 4);
+#define FP_DWPW_WPK(NBV, SV)                                                                                     \
+  do {                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)dwpw_wp_kernel<NBV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                              (int)wlds);                                                                       \
+    hipLaunchKernelGGL((dwpw_wp_kernel<NBV, SV>), dim3(nwg), dim3(256), wlds, s, b);                             \
+  } while (0)
+        if (NB == 2) { if (op.stride == 1) FP_DWPW_WPK(2, 1); else FP_DWPW_WPK(2, 2); }
+        else FP_DWPW_WPK(4, 1);
+#undef FP_DWPW_WPK
+        FP_CHECK_LAUNCH();
+        return FP_OK;
+      }
       if (NB == 2) { if (op.stride == 1) FP_DWPW_PERSIST(2, 1); else FP_DWPW_PERSIST(2, 2); }
       else FP_DWPW_PERSIST(4, 1);
 #undef FP_DWPW_PERSIST

@@ -352,9 +352,9 @@ def test_mobilefacenet_fused_and_unfused_plans_agree(dev):
 
 
 @pytest.mark.parametrize("cin,cout,groups,stride,hw,residual,n", [
-    (64, 64, 128, 1, 28, True, 176),     # dwpw_persist<2,1> + pws<64>, whole tiles
+    (64, 64, 128, 1, 28, True, 176),     # dwpw_wp<2,1> + pws<64>, whole tiles
     (64, 64, 128, 1, 28, True, 169),     # partial last patch tile; M % 32 != 0 -> conv_igemm for the expand conv
-    (64, 64, 128, 2, 56, False, 168),    # dwpw_persist<2,2>
+    (64, 64, 128, 2, 56, False, 168),    # dwpw_wp<2,2>
     (128, 128, 256, 1, 14, True, 672),   # dwpw_persist<4,1> + pws<128>
 ])
 def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, stride, hw, residual, n):
@@ -371,7 +371,9 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
     y = blk.emit(pb, inp.view())
     plan = CompiledPlan(pb, dev)
     names = [plan.kernel_name(i) for i in range(plan.n_ops)]
-    assert any(k.startswith("dwpw_persist_kernel") for k in names), names
+    # 28 x 28 / 56 x 56 shapes: the wave-private kernel (projection weights resident in LDS); 14 x 14: the workgroup one
+    want = "dwpw_persist_kernel" if groups * cout * 4 > 64 * 1024 else "dwpw_wp_kernel"
+    assert any(k.startswith(want) for k in names), names
     m_rows = n * hw * hw
     assert any(k.startswith("pws_kernel") for k in names) == (m_rows % 32 == 0), names
     t = plan.buf_tensor(inp, n)
@@ -441,7 +443,7 @@ def test_dwpw_with_output_prelu_vs_torch(dev, n, hw):
     out = pb.new_buf(hw, hw, cout)
     pb.dwpw(inp.view(), dw_w, ds, db, dsl, pw_w, ps, pbi, out.view(), 1, out_slope=psl)
     plan = CompiledPlan(pb, dev)
-    assert plan.kernel_name(0).startswith("dwpw_persist_kernel") == (n * hw * hw >= 131072), plan.kernel_name(0)
+    assert plan.kernel_name(0).startswith("dwpw_wp_kernel") == (n * hw * hw >= 131072), plan.kernel_name(0)
     t = plan.buf_tensor(inp, n)
     t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
     plan.run()
