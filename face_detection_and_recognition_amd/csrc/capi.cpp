@@ -212,7 +212,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
       return buf;
     case FP_OP_DWPW:
       if (fp_dwpw_persistent(*op)) {
-        snprintf(buf, sizeof(buf), "%s<%d, %d>", fp_dwpw_wave_private(*op) ? "dwpw_wp_kernel" : "dwpw_persist_kernel",
+        snprintf(buf, sizeof(buf), fp_dwpw_wave_private(*op) ? "dwpw_wp_kernel<%d, %d, 4>" : "dwpw_persist_kernel<%d, %d>",
                  (int)fp_round_up(op->Cout, 32) / 32, op->stride);
         return buf;
       }

@@ -605,8 +605,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_persist_kernel(DwPwArgs p) {
 // -> depthwise + affine + PReLU -> its private A tile in LDS -> MFMAs against the projection weights resident in LDS
 // -> (after the last chunk) epilogue staged in the same private rows -> 16-byte stores.  The only barrier is the one
 // after the weights are staged; the 8 waves of a CU drift apart and fill each other's gaps.
-template <int NB, int S>
-__global__ __launch_bounds__(256, 2) void dwpw_wp_kernel(DwPwArgs p) {
+template <int NB, int S, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 6 ? 3 : 2) void dwpw_wp_kernel(DwPwArgs p) {
   constexpr int BN = NB * 32;
   constexpr int WR = S + 3;   // window rows = window columns
   constexpr int WV = 32 * PLDT + 32;    // floats per wave region: A tile [32][PLDT], then Mrow[32]
@@ -615,31 +615,31 @@ __global__ __launch_bounds__(256, 2) void dwpw_wp_kernel(DwPwArgs p) {
   float* Ws = smem;                     // [12][G]     taps 0..8, scale, bias, slope (ones without PReLU)
   float* Osl = Ws + 12 * Gc;            // [BN]        output PReLU slopes (ones without one)
   float* W2s = Osl + BN;                // [G/4][BN][4] packed projection weights, all chunks
-  float* Wv = W2s + Gc * BN;            // 4 wave regions
+  float* Wv = W2s + Gc * BN;            // NW wave regions
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, h = lane >> 5;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 
-  for (int i = tid; i < 3 * Gc; i += 256) {   // 12*G/4 float4s
+  for (int i = tid; i < 3 * Gc; i += NW * 64) {   // 12*G/4 float4s
     const int row = (i * 4) / Gc;
     f32x4 v = {1.f, 1.f, 1.f, 1.f};
     if (row < 11 || p.has_slope) v = *(const f32x4*)(p.dwp + (long)i * 4);
     *(f32x4*)&Ws[i * 4] = v;
   }
   if (tid < BN) Osl[tid] = (p.oslope && tid < p.Cout) ? p.oslope[tid] : 1.f;
-  for (int i = tid; i < (Gc * BN) / 4; i += 256) *(f32x4*)&W2s[i * 4] = *(const f32x4*)(p.pwp + (long)i * 4);
+  for (int i = tid; i < (Gc * BN) / 4; i += NW * 64) *(f32x4*)&W2s[i * 4] = *(const f32x4*)(p.pwp + (long)i * 4);
 
   float* At = Wv + wave * WV;           // [32][PLDT]  this wave's depthwise output; epilogue staging
   int* Mrow = (int*)(At + 32 * PLDT);   // [32]        output pixel index of each tile row (-1: past the end)
 
   // wave-level virtual blocks: wave w of workgroup b is virtual block 4*pos(b) + w of NV = 4 * gridDim.x; a workgroup's
   // four waves take four consecutive 8-patch tiles (their windows overlap: L1)
-  const int NV = gridDim.x * 4;
+  const int NV = gridDim.x * NW;
   int vb;
   {
     const int G = gridDim.x, b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
-    vb = ((xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k) * 4 + wave;
+    vb = ((xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k) * NW + wave;
   }
   const int nch = Gc / PKC;
   const int c = (lane & 7) * 4;     // this lane's 4 channels inside a chunk
@@ -651,8 +651,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_wp_kernel(DwPwArgs p) {
   long pk = 0;
   long ptile = vb;
   int pch = 0;
-  long rowoff[WR];
-  int coloff[WR];
+  unsigned rowoff[WR];   // byte offsets from p.in (the launcher checks the tensor is < 4 GiB)
+  unsigned coloff[WR];
   unsigned xmask = 0;                // bit wy*WR+wx: window position inside the image (else zero padding)
   auto decode = [&](long tile) {
     unsigned pi = (unsigned)tile * 8u + (unsigned)g;
@@ -664,8 +664,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_wp_kernel(DwPwArgs p) {
 #pragma unroll
     for (int w = 0; w < WR; ++w) {
       const int iy = iy0 + w, ix = ix0 + w;
-      rowoff[w] = (long)img * p.in_ns + c + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
-      coloff[w] = min(max(ix, 0), p.W - 1) * p.in_ld;
+      rowoff[w] = (img * (unsigned)p.in_ns + (unsigned)c + (unsigned)min(max(iy, 0), p.H - 1) * (unsigned)(p.W * p.in_ld)) * 4u;
+      coloff[w] = (unsigned)(min(max(ix, 0), p.W - 1) * p.in_ld) * 4u;
       if ((unsigned)iy < (unsigned)p.H) rowv |= 1u << w;
       if ((unsigned)ix < (unsigned)p.W) colv |= 1u << w;
     }
@@ -676,11 +676,11 @@ __global__ __launch_bounds__(256, 2) void dwpw_wp_kernel(DwPwArgs p) {
   };
   f32x4 x[WR][WR];
   auto issue_loads = [&](int ch) {   // raw (clamped-address) window; the padding mask is applied when it is consumed
-    const float* ib = p.in + ch * PKC;
+    const char* ib = (const char*)(p.in + ch * PKC);
 #pragma unroll
     for (int wy = 0; wy < WR; ++wy)
 #pragma unroll
-      for (int wx = 0; wx < WR; ++wx) x[wy][wx] = *(const f32x4*)(ib + rowoff[wy] + coloff[wx]);
+      for (int wx = 0; wx < WR; ++wx) x[wy][wx] = *(const f32x4*)(ib + (rowoff[wy] + coloff[wx]));
   };
   if (ptile < ntw) {
     decode(ptile);
@@ -864,7 +864,8 @@ bool fp_dwpw_persistent(const fp_op& op) {
 // The persistent shapes whose whole packed projection matrix (G x Npad floats) fits 64 KB of LDS take the wave-private
 // kernel: every Mobile-FaceNet block on the 56 x 56 and 28 x 28 maps (the 14 x 14 blocks have 128 KB of it).
 bool fp_dwpw_wave_private(const fp_op& op) {
-  return fp_dwpw_persistent(op) && (size_t)op.Cin * fp_round_up(op.Cout, 32) * 4 <= 64 * 1024;
+  return fp_dwpw_persistent(op) && (size_t)op.Cin * fp_round_up(op.Cout, 32) * 4 <= 64 * 1024 &&
+         (unsigned long long)op.N * (unsigned long long)op.in_ns * 4ull < (1ull << 32);   // 32-bit byte offsets
 }
 
 #ifdef FP_DWPW_STAMPS
@@ -927,16 +928,19 @@ int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStrea
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                         \
     hipLaunchKernelGGL((dwpw_persist_kernel<NBV, SV>), dim3(nblk), dim3(256), plds, s, b);                      \
   } while (0)
-      if (fp_dwpw_wave_private(op)) {   // whole projection matrix resident in LDS: the wave-private kernel
-        const size_t wlds = 4 * ((size_t)12 * a.G + (size_t)NB * 32 + (size_t)a.G * NB * 32 + 4 * (size_t)(32 * PLDT + 32));
+      if (fp_dwpw_wave_private(op)) {
+        // whole projection matrix resident in LDS: the wave-private kernel, 4 waves per workgroup, 2 workgroups per CU
+        // (6 waves x 2 -- three per SIMD -- needs <= 168 VGPRs: the NB = 2 form spills 92 bytes there and runs 2x slower)
+        constexpr int NWv = 4;
+        const size_t wlds = 4 * ((size_t)12 * a.G + (size_t)NB * 32 + (size_t)a.G * NB * 32 + NWv * (size_t)(32 * PLDT + 32));
         const long ntw = ((long)op.N * (op.OH / 2) * (op.OW / 2) + 7) / 8;
         int nwg = 512;
-        if ((long)nwg * 4 > ntw) nwg = (int)((ntw + 3) / 4);
+        if ((long)nwg * NWv > ntw) nwg = (int)((ntw + NWv - 1) / NWv);
 #define FP_DWPW_WPK(NBV, SV)                                                                                     \
   do {                                                                                                          \
-    (void)hipFuncSetAttribute((const void*)dwpw_wp_kernel<NBV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+    (void)hipFuncSetAttribute((const void*)dwpw_wp_kernel<NBV, SV, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)wlds);                                                                       \
-    hipLaunchKernelGGL((dwpw_wp_kernel<NBV, SV>), dim3(nwg), dim3(256), wlds, s, b);                             \
+    hipLaunchKernelGGL((dwpw_wp_kernel<NBV, SV, NWv>), dim3(nwg), dim3(NWv * 64), wlds, s, b);                   \
   } while (0)
         if (NB == 2) { if (op.stride == 1) FP_DWPW_WPK(2, 1); else FP_DWPW_WPK(2, 2); }
         else FP_DWPW_WPK(4, 1);
