@@ -356,6 +356,7 @@ def test_mobilefacenet_fused_and_unfused_plans_agree(dev):
     (64, 64, 128, 1, 28, True, 169),     # partial last patch tile; M % 32 != 0 -> conv_igemm for the expand conv
     (64, 64, 128, 2, 56, False, 168),    # dwpw_wp<2,2>
     (128, 128, 256, 1, 14, True, 672),   # dwpw_persist<4,1> + pws<128>
+    (128, 128, 256, 1, 14, False, 379),  # ... without residual, ragged last tile
 ])
 def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, stride, hw, residual, n):
     """The persistent / streaming kernels (csrc/dwpw.hip dwpw_persist_kernel, csrc/pws.hip) only take over above
