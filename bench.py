@@ -278,7 +278,10 @@ def run_pipeline(args):
                 "algorithmic_bytes_per_launch": int(bytes_tot / max(launches, 1)),
                 "share_of_network_kernel_time": round(probe_share, 3),
                 "pipeline_algorithmic_GBps": round(pipe_bytes / step_s / 1e9, 1),
-                "pipeline_frac": round(pipe_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4)}
+                "pipeline_frac": round(pipe_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                "model": "achieved / frac: SURVEY 8(d) op-granular bytes -- a fused kernel is charged for every tensor "
+                         "pass of the reference ops it replaces (4 per BlazeBlock, it moves 2), so frac can exceed 1; "
+                         "hbm_frac_from_traffic: bytes the memory system moved (PMC) / launch time / peak"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
