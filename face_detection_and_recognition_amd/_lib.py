@@ -63,6 +63,7 @@ _I64 = C.c_int64
 # name -> (restype, argtypes); every symbol declared in include/facepath.h
 SIGNATURES = {
     "fp_abi_version": (_I, []),
+    "fp_selftest": (_I, []),
     "fp_strerror": (C.c_char_p, [_I]),
     "fp_last_hip_error": (C.c_char_p, []),
     "fp_plan_run": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P]),

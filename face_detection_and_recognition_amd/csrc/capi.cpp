@@ -19,6 +19,40 @@ int fp_abi_version(void) { return FP_ABI_VERSION; }
 
 const char* fp_last_hip_error(void) { return g_hip_err; }
 
+// host mirror of the device-side fp_fastdiv (common.h): __umulhi(n, mul) >> shift
+static unsigned fastdiv_host(unsigned n, fp_divisor d) { return (unsigned)(((unsigned long long)n * d.mul) >> 32) >> d.shift; }
+
+int fp_selftest(void) {
+  auto check = [&](unsigned d) -> bool {
+    const fp_divisor dv = fp_make_divisor(d);
+    const unsigned nmax = 0x7fffffffu, qmax = nmax / d;
+    const unsigned qs[] = {0u, 1u, 2u, qmax / 3, qmax / 2, qmax - 1, qmax};
+    for (unsigned q : qs) {
+      const unsigned long long lo = (unsigned long long)q * d;
+      const unsigned long long cand[] = {lo, lo + 1, lo + d - 1, lo + d / 2};
+      for (unsigned long long n64 : cand) {
+        if (n64 > nmax) continue;
+        const unsigned n = (unsigned)n64;
+        if (fastdiv_host(n, dv) != n / d) {
+          snprintf(g_hip_err, sizeof(g_hip_err), "fp_fastdiv(%u, %u) = %u, expected %u", n, d, fastdiv_host(n, dv), n / d);
+          return false;
+        }
+      }
+    }
+    if (fastdiv_host(nmax, dv) != nmax / d) {
+      snprintf(g_hip_err, sizeof(g_hip_err), "fp_fastdiv(%u, %u) wrong at the top of the range", nmax, d);
+      return false;
+    }
+    return true;
+  };
+  for (unsigned d = 2; d <= 4096; ++d)
+    if (!check(d)) return FP_ERR_INVALID_ARG;
+  const unsigned big[] = {4097u, 12321u, 16384u, 65535u, 65536u, 65537u, 1000003u, 16777216u, 123456789u, 1u << 30, (1u << 30) + 1u};
+  for (unsigned d : big)
+    if (!check(d)) return FP_ERR_INVALID_ARG;
+  return FP_OK;
+}
+
 const char* fp_strerror(int status) {
   switch (status) {
     case FP_OK: return "ok";

@@ -43,6 +43,13 @@ int fp_abi_version(void);
 const char* fp_strerror(int status);
 /* Last HIP error string seen by this thread's failing call ("" if none). */
 const char* fp_last_hip_error(void);
+/*
+ * Host-only consistency check of the library's integer helpers (no GPU needed): the reciprocal-multiply division the
+ * persistent kernels use for pixel -> (image, row, column) decode, fp_make_divisor / fp_fastdiv, against the hardware
+ * division for every divisor 2 .. 4096 and selected ones up to 2^30, at the boundaries of each quotient and at 2^31 - 1.
+ * Returns FP_OK or FP_ERR_INVALID_ARG (with the failing pair in fp_last_hip_error's buffer).
+ */
+int fp_selftest(void);
 
 /* ------------------------------------------------------------------------- */
 /* 1. Network plans: one flat array of ops, executed back-to-back on a stream. */

@@ -30,6 +30,12 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.fp_strerror(-2).decode().startswith("op touches")
 
 
+def test_library_selftest_of_integer_helpers(lib):
+    """fp_selftest: the reciprocal-multiply division of the persistent kernels (csrc/common.h fp_make_divisor /
+    fp_fastdiv) equals n // d for every divisor 2..4096 and a set of large ones, at quotient boundaries up to 2^31 - 1."""
+    assert lib.fp_selftest() == 0, lib.fp_last_hip_error().decode()
+
+
 def test_struct_layout_matches_header():
     # 22 int32 + 10 int64 + 2 int32 (act2, flags) = 176 bytes; fp_resize_item = 9 int32; fp_ext = pointer + size_t
     assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8 + 2 * 4
