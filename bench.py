@@ -2,6 +2,7 @@
 """Headline benchmark: faces/sec end-to-end (detect -> embed -> cosine-filter) on synthetic 576x1024 frames,
 batch 256 per GPU (BASELINE.json configs[1]: BlazeFace back-camera 256^2 -> Mobile-FaceNet 112^2 -> cosine filter).
 
+  python bench.py                         # 1 GPU, 200 timed steps after 10 warm-ups
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
@@ -376,8 +377,9 @@ def run_c5(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 200 timed steps (~1.3 s of GPU time: long enough for a utilisation sampler to see it) after 10 warm-ups
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["pipeline", "c5"], default="pipeline")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
