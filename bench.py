@@ -378,8 +378,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 200 timed steps (~1.3 s of GPU time: long enough for a utilisation sampler to see it) after 10 warm-ups
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    # (the c5 workload's step is ~60-90 ms: 20 / 3 there)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=["pipeline", "c5"], default="pipeline")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -387,6 +388,10 @@ def main():
                     help="synthetic detector's box size (model-input pixels); sets how candidates cluster in the NMS")
     ap.add_argument("--gallery-rows", type=int, default=125_000, help="c5: gallery rows per rank")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.workload == "c5" else 200
+    if args.warmup is None:
+        args.warmup = 3 if args.workload == "c5" else 10
     if args.workload == "c5":
         run_c5(args)
     else:
