@@ -11,11 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfacepath.so")
 
 FP_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_YSTEM_U8, OP_STEM_U8 = 10, 11
+OP_YSTEM_U8, OP_STEM_U8, OP_DWBLOCK = 10, 11, 12
 # fp_act
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
 # fp_res_mode
@@ -40,6 +40,7 @@ class FpOp(C.Structure):
         ("in_off", C.c_int64), ("out_off", C.c_int64), ("res_off", C.c_int64),
         ("w_off", C.c_int64), ("scale_off", C.c_int64), ("bias_off", C.c_int64), ("slope_off", C.c_int64),
         ("act2", C.c_int32), ("flags", C.c_int32),
+        ("Cmid", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

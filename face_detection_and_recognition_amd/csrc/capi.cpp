@@ -76,7 +76,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
   const bool ext_in = op.kind == FP_OP_YSTEM_U8 || op.kind == FP_OP_STEM_U8;   // input in an external buffer (checked at launch)
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
-                    op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
+                    op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
+  if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
   if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3)) return FP_ERR_INVALID_ARG;
@@ -112,7 +113,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
-      op.kind == FP_OP_DWPW || op.kind == FP_OP_YSTEM || ext_in) {
+      op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_YSTEM || ext_in) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -150,6 +151,14 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   } else if (op.act2 != FP_ACT_NONE) {
     return FP_ERR_INVALID_ARG;
   }
+  if (op.kind == FP_OP_DWBLOCK) {
+    // w_off: expand packed as CONV (K = Cin, Npad = Cmid); scale_off: [15][Cmid]; slope_off: project packed as CONV
+    // (K = Cmid, Npad = Cout) + [Cout] scale + [Cout] bias.  The shapes the kernel exists for are fp_dwblock_supported's.
+    if (!fp_dwblock_supported(op)) return FP_ERR_UNSUPPORTED;
+    if (!span_ok(op.w_off, (int64_t)op.Cin * op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
+    if (!span_ok(op.scale_off, 15 * (int64_t)op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
+    if (!span_ok(op.slope_off, (int64_t)op.Cmid * op.Cout + 2 * (int64_t)op.Cout, weight_floats)) return FP_ERR_BOUNDS;
+  }
   if (op.kind == FP_OP_YSTEM || op.kind == FP_OP_YSTEM_U8) {
     if (op.Cin != (ext_in ? 3 : 4) || op.res_C <= 0 || op.res_C > 32 || op.Cout > 32) return FP_ERR_UNSUPPORTED;
     if (op.res_H <= 0 || op.res_W <= 0 || op.res_ld < op.res_C || op.res_ns < 0) return FP_ERR_INVALID_ARG;
@@ -169,7 +178,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.act == FP_ACT_PRELU && op.slope_off < 0) return FP_ERR_INVALID_ARG;
     if (op.act < FP_ACT_NONE || op.act > FP_ACT_SILU) return FP_ERR_INVALID_ARG;
   }
-  if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW) && op.res_mode != FP_RES_NONE) {
+  if ((op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK) &&
+      op.res_mode != FP_RES_NONE) {
     if (op.res_mode < FP_RES_NONE || op.res_mode > FP_RES_SHUFFLE2) return FP_ERR_INVALID_ARG;
     if (op.res_mode == FP_RES_SHUFFLE2 &&
         ((op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW) || op.out_cmul != 1 || op.out_ld < 2 * op.Cout))
@@ -193,6 +203,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_L2NORM:
     case FP_OP_BLAZEBLOCK:
     case FP_OP_DWPW:
+    case FP_OP_DWBLOCK:
     case FP_OP_YSTEM:
     case FP_OP_YSTEM_U8:
     case FP_OP_STEM_U8:
@@ -253,6 +264,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;
+    case FP_OP_DWBLOCK:
+      snprintf(buf, sizeof(buf), "dwblock_kernel<%d, %d, %d, %d>", op->Cin, op->H, op->H == 28 ? 7 : op->H, op->H == 7 ? 2 : 1);
+      return buf;
     case FP_OP_STEM_U8:
       snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d, true>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
@@ -283,6 +297,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_L2NORM: return fp_launch_l2norm(op, arena, s);
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
     case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
+    case FP_OP_DWBLOCK: return fp_launch_dwblock(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);
     case FP_OP_STEM_U8: return fp_launch_stem_u8(op, weights, arena, ext, n_ext, s);

@@ -81,6 +81,8 @@ bool fp_blazeblock_fixed24(const fp_op& op);   // persistent BlazeBlock instanti
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel / dwpw_wp_kernel, false: dwpw_kernel
 bool fp_dwpw_wave_private(const fp_op& op); // true: dwpw_wp_kernel (projection weights resident in LDS)
+bool fp_dwblock_supported(const fp_op& op); // whole Depth_Wise block shapes dwblock.hip is instantiated for
+int fp_launch_dwblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take the wave-private streaming kernel
 int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)

@@ -84,12 +84,21 @@ class Depth_Wise(_NoCompute):
         self.residual = residual
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
+    FUSE_BLOCK = True       # whole block as FP_OP_DWBLOCK where csrc/dwblock.hip has the shape (stride-1 blocks)
+    FUSE_BLOCK_MIN_N = 64   # below this batch capacity a tile-per-workgroup kernel cannot fill the chip
 
     def emit(self, pb, x, expanded=None):
         """expanded: the output of self.conv when the caller has already produced it (fused into the previous
         depthwise Conv_block, see MobileFaceNet._emit); x is then only the residual source."""
+        dw, pj, ex = self.conv_dw, self.project, self.conv
+        if (Depth_Wise.FUSE and Depth_Wise.FUSE_BLOCK and expanded is None and pb.N >= Depth_Wise.FUSE_BLOCK_MIN_N and
+                dw.k == 3 and dw.p == 1 and pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
+            y = pb.new_buf(x.H, x.W, pj.out_c)
+            pb.dwblock(x, npy(ex.conv.weight), _affine(ex.bn), npy(ex.prelu.weight),
+                       npy(dw.conv.weight), _affine(dw.bn), npy(dw.prelu.weight),
+                       npy(pj.conv.weight), _affine(pj.bn), y.view(), self.residual)
+            return y
         a = expanded if expanded is not None else self.conv.emit(pb, x)
-        dw, pj = self.conv_dw, self.project
         if (Depth_Wise.FUSE and dw.k == 3 and dw.p == 1 and dw.groups % 64 == 0 and pj.out_c % 4 == 0 and
                 pj.out_c <= 128):
             OH = (a.H + 2 - 3) // dw.s + 1

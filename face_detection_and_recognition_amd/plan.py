@@ -360,6 +360,45 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * G + opix * G + opix * G + opix * cout))
         return out
 
+    # shapes csrc/dwblock.hip is instantiated for: (block width, map size); Cmid = 2 * width
+    DWBLOCK_SHAPES = ((128, 14), (128, 7), (64, 28))
+
+    @classmethod
+    def dwblock_supported(cls, x, cin, cmid, cout, stride):
+        """Mirror of fp_dwblock_supported (csrc/dwblock.hip): stride-1 Depth_Wise blocks on a dense square map."""
+        return (stride == 1 and cin == cout and cmid == 2 * cin and x.H == x.W and (cin, x.H) in cls.DWBLOCK_SHAPES and
+                x.coff == 0 and x.C == cin and x.buf.ld == cin and x.buf.ns == x.H * x.W * cin and not x.buf.rowpad)
+
+    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual):
+        """A whole Depth_Wise block (mobile_facenet.py:67-88) as ONE op (FP_OP_DWBLOCK, csrc/dwblock.hip): 1x1 expand
+        + BN + PReLU -> dw3x3 (stride 1) + BN + PReLU -> 1x1 project + BN [+ x]; the expanded tensor stays in LDS.
+        *_aff = (scale, bias) of the eval-mode BatchNorm."""
+        cmid, cin = e_w.shape[0], e_w.shape[1]
+        cout = pw_w.shape[0]
+        assert self.dwblock_supported(x, cin, cmid, cout, 1) and dw_w.shape == (cmid, 1, 3, 3) and pw_w.shape[1] == cmid
+        assert out.coff == 0 and out.C == cout and out.buf.ld == cout and out.cmul == 1 and not out.buf.rowpad
+        op = self._base(L.OP_DWBLOCK, x, out, out.H, out.W)
+        op.Cout, op.Cmid = cout, cmid
+        op.KH = op.KW = 3
+        op.stride = 1
+        op.pad_t = op.pad_l = 1
+        op.act = L.ACT_PRELU
+        op.w_off = self.add_weight(pack_conv_weight(e_w, cin, cmid))
+        rows = [pad_vec(e_aff[0], cmid), pad_vec(e_aff[1], cmid), pad_vec(e_slope, cmid), pack_dw_weight(dw_w, cmid),
+                pad_vec(dw_aff[0], cmid), pad_vec(dw_aff[1], cmid), pad_vec(dw_slope, cmid)]
+        op.scale_off = self.add_weight(np.concatenate(rows))
+        op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(pw_w, cmid, cout), pad_vec(pw_aff[0], cout),
+                                                       pad_vec(pw_aff[1], cout)]))
+        if residual:
+            op.res_mode = L.RES_ADD_AFTER_ACT
+            op.res_ld, op.res_ns, op.res_off = op.in_ld, op.in_ns, op.in_off
+            op.res_C, op.res_H, op.res_W = cin, x.H, x.W
+        self.ops.append(op)
+        pix = x.H * x.W
+        # SURVEY 8(d): the three convs of the block, each input once + output once
+        self.alg_bytes.append(4 * self.N * pix * ((cin + cmid) + (cmid + cmid) + (cmid + cout)))
+        return out
+
     def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
         """First conv of a network reading u8 frames itself (FP_OP_STEM_U8): KxK (3 or 5) stride 2, Cout <= 64, dense
         output buffer.  u8 = (H, W, frame_h, frame_w, ext_index): the H x W letterbox canvas is resampled from the

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 3
+#define FP_ABI_VERSION 4
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -68,8 +68,11 @@ enum fp_op_kind {
                            stem_2a (1x1, SiLU) -> out, and maxpool2x2(stem_1) -> res view (the concat half stem_3 reads) */
   FP_OP_YSTEM_U8 = 10,  /* FP_OP_YSTEM reading the u8 frames directly: the letterbox (fp_resize_normalize's arithmetic through
                            fp_letterbox_tables) happens while the input tile is staged; needs fp_plan_run_ext */
-  FP_OP_STEM_U8 = 11    /* first conv of a network (KxK in {3,5}, stride 2, Cout <= 64, dense NHWC output; BlazeFace's stem,
+  FP_OP_STEM_U8 = 11,   /* first conv of a network (KxK in {3,5}, stride 2, Cout <= 64, dense NHWC output; BlazeFace's stem,
                            blazeface.py:118-120,195) reading the u8 frames the same way; needs fp_plan_run_ext */
+  FP_OP_DWBLOCK = 12    /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
+                           dw3x3 stride 1 (+BN, PReLU) -> 1x1 project (+BN) [+ x]; the expanded tensor (Cmid channels)
+                           lives in LDS only.  Shapes: see "DWBLOCK" below; anything else fails validation */
 };
 
 enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
@@ -112,6 +115,8 @@ typedef struct fp_op {
   int64_t w_off, scale_off, bias_off, slope_off;
   int32_t act2;                    /* fused ops: activation of the SECOND conv's output (DWPW: FP_ACT_NONE / FP_ACT_SILU) */
   int32_t flags;                   /* FP_OPF_* bits (0 for dense tensors) */
+  int32_t Cmid;                    /* ABI 4.  DWBLOCK: channels of the expanded tensor (Depth_Wise `groups`); 0 elsewhere */
+  int32_t reserved0;               /* ABI 4.  must be 0 */
 } fp_op;
 
 /*
@@ -166,6 +171,19 @@ typedef struct fp_op {
  *   STEM_U8 : a CONV (weights packed for Cin = 4: k = tap*4 + c, zero fourth channel; scale / bias / slope / act as
  *            CONV, no residual) whose H x W input is the letterbox canvas of external u8 frames: in_off = e with
  *            ext[e .. e+2] = frames, tap tables, LUT as for YSTEM_U8; Cin = 3, res_H = fh, res_W = fw.
+ */
+
+/*
+ *   DWBLOCK : in = x [N][H][W][Cin] dense NHWC, out = y [N][H][W][Cout], Cout == Cin, stride 1, pad 1, KH = KW = 3.
+ *            (Cin, H = W) in {(128, 14), (128, 7), (64, 28)} (every residual block of Mobile-FaceNet,
+ *            mobile_facenet.py:119-122,126-130), Cmid a multiple of 32.  res_mode = FP_RES_ADD_AFTER_ACT adds x itself
+ *            (the res_* view must be the in_* view), FP_RES_NONE omits the shortcut.
+ *            w_off     -> expand weights packed as CONV (K = Cin, Npad = Cmid)
+ *            scale_off -> [15][Cmid]: rows 0..2 expand BN scale / BN bias / PReLU slope, rows 3..11 the depthwise taps
+ *                         (ky*3 + kx), rows 12..14 depthwise BN scale / BN bias / PReLU slope
+ *            slope_off -> project weights packed as CONV (K = Cmid, Npad = Cout), then [Cout] BN scale, [Cout] BN bias
+ * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
+ * views; 4 = fp_op.Cmid / reserved0 and FP_OP_DWBLOCK.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -369,7 +369,11 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
     x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
     pb = PlanBuilder(n)
     inp = pb.new_buf(hw, hw, cin)
-    y = blk.emit(pb, inp.view())
+    Depth_Wise.FUSE_BLOCK = False      # the two-launch form (still what stride-2 blocks and small batches run)
+    try:
+        y = blk.emit(pb, inp.view())
+    finally:
+        Depth_Wise.FUSE_BLOCK = True
     plan = CompiledPlan(pb, dev)
     names = [plan.kernel_name(i) for i in range(plan.n_ops)]
     # 28 x 28 / 56 x 56 shapes: the wave-private kernel (projection weights resident in LDS); 14 x 14: the workgroup one
@@ -387,6 +391,74 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
                                         stride, residual).numpy()
     assert got.shape == ref.shape
     assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("cin,hw,residual,n", [
+    (128, 14, True, 70),    # whole-image tiles
+    (128, 14, False, 3),    # no shortcut, fewer tiles than CUs
+    (64, 28, True, 37),     # four 7-row bands per image, halo rows recomputed, zero rows at the image border
+    (64, 28, False, 2),
+    (128, 7, True, 65),     # two images per tile, odd batch: the last tile holds one image
+    (128, 7, False, 4),
+    (128, 14, True, 530),   # bench-like batch: more tiles than resident workgroups
+])
+def test_dwblock_whole_depth_wise_vs_oracle(dev, cin, hw, residual, n):
+    """FP_OP_DWBLOCK (csrc/dwblock.hip): expand -> depthwise -> project [+ x] of a stride-1 Depth_Wise block in one
+    kernel, the expanded tensor kept in LDS, against mobilefacenet_ref._depth_wise (torch fp32 on the CPU;
+    mobile_facenet.py:77-88).  Inputs have |x| ~ 1 and the output is compared to 1e-5 of its scale and, element by
+    element, to 2e-5 absolute + 1e-5 relative."""
+    rng = np.random.default_rng(3000 + hw + n)
+    blk = Depth_Wise(cin, cin, residual=residual, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=2 * cin)
+    sd = synth_state_dict(blk.state_dict(), 1200 + cin + hw)
+    blk.load_state_dict(sd)
+    x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, cin)
+    old = Depth_Wise.FUSE_BLOCK_MIN_N
+    Depth_Wise.FUSE_BLOCK_MIN_N = 1
+    try:
+        y = blk.emit(pb, inp.view())
+    finally:
+        Depth_Wise.FUSE_BLOCK_MIN_N = old
+    plan = CompiledPlan(pb, dev)
+    assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_kernel"), [plan.kernel_name(i) for i in range(plan.n_ops)]
+    t = plan.buf_tensor(inp, n)
+    t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(y, n)
+    out_t.fill_(float("nan"))                   # every output element must be written
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.permute(0, 3, 1, 2).cpu().numpy()
+    ref = mobilefacenet_ref._depth_wise({k: torch.as_tensor(v) for k, v in sd.items()}, "", torch.from_numpy(x),
+                                        1, residual).numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert rel_err(got, ref) < 1e-5
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(t.permute(0, 3, 1, 2).cpu().numpy(), x)   # the input is only read
+
+
+def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
+    """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through a plan whose twelve
+    stride-1 Depth_Wise blocks are FP_OP_DWBLOCK (batch capacity 64, run on the golden's 4 images), and the same
+    images through the two-launch plan: both within the north_star's 1e-4 of the reference, 2e-6 of each other."""
+    g = golden("mobilefacenet_forward")
+    net = MobileFaceNet(512)
+    net.load_state_dict(synth_state_dict(net.state_dict(), int(g["seed"])))
+    net = net.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    n = x.shape[0]
+    plan = net.plan_for(64)
+    kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
+    assert kinds.count(L.OP_DWBLOCK) == 12
+    plan.input[:n, ..., :3].copy_(x.permute(0, 2, 3, 1))
+    plan.input[:n, ..., 3:].zero_()
+    plan.run(n)
+    torch.cuda.synchronize()
+    e = plan.out[:n].cpu().numpy().copy()
+    assert np.abs(e - g["emb"]).max() < 1e-4
+    small = net(torch.from_numpy(g["x"])).cpu().numpy()
+    assert L.OP_DWBLOCK not in [net.plan_for(n).ops[i].kind for i in range(net.plan_for(n).n_ops)]
+    assert np.abs(e - small).max() < 2e-6
 
 
 @pytest.mark.parametrize("ks,cout,hw,n,act", [(5, 24, 256, 8, "relu"), (3, 64, 112, 48, "prelu"), (3, 24, 90, 70, "none")])

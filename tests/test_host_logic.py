@@ -38,7 +38,7 @@ def test_library_selftest_of_integer_helpers(lib):
 
 def test_struct_layout_matches_header():
     # 22 int32 + 10 int64 + 2 int32 (act2, flags) = 176 bytes; fp_resize_item = 9 int32; fp_ext = pointer + size_t
-    assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8 + 2 * 4
+    assert ctypes.sizeof(L.FpOp) == 22 * 4 + 10 * 8 + 4 * 4
     assert ctypes.sizeof(L.FpExt) == 16
     assert ctypes.sizeof(L.FpResizeItem) == 36
 
