@@ -3,24 +3,28 @@
 // Depth_Wise.forward (fde/modules/mobile_facenet/mobile_facenet.py:77-88) is
 //     conv (1x1 expand C -> G, BN, PReLU) -> conv_dw (3x3 depthwise, BN, PReLU) -> project (1x1 G -> C, BN) [+ x].
 // Round 2 ran it as two launches (pws.hip: expand, dwpw.hip: depthwise + project) with the G-channel tensor written
-// to HBM by the first and read back by the second.  Here it never leaves the CU:
+// to HBM by the first and read back by the second.  Here it never leaves the CU.
 //
-//   tile   = 196 output pixels: a whole 14x14 image, 7 rows of a 28x28 image (+ one halo row on either side whose
-//            expand values are recomputed), or two 7x7 images;
-//   round  = 32 expanded channels; per round, two phases separated by workgroup barriers
-//     phase 1 (matrix pipe)  P(c-1): D-tile (LDS) x project weights (registers) accumulated into the output tile that
-//                            the four waves keep in registers (wave w owns output channels [w*C/4, (w+1)*C/4));
-//                            E(c):   x (straight from L2 into MFMA A fragments) x expand weights (LDS / registers)
-//                            -> BN + PReLU -> E-image in LDS (row-padded: one zero pixel after every row, zero rows
-//                            between / around images, so the depthwise taps need no bounds checks);
-//     phase 2 (VALU)         D(c):   3x3 depthwise + BN + PReLU from the E-image -> D-tile [208][32+4] in LDS;
-//                            the next round's weights are staged meanwhile.
-//   Two workgroups per CU (<= 80 KiB LDS, <= 256 VGPRs each): while one is in its VALU phase or waits at a barrier
-//   the other one's MFMAs fill the SIMD's matrix pipe — the phases of ONE workgroup never overlap, and do not need to.
-//   v_mfma_f32_16x16x4_f32: 196 pixels are 12.25 tiles of 16 rows (13, 6 % padding) but 6.1 of 32 (7, 14 %).
+//   tile  = one 512-thread workgroup = 196 (147) output pixels: a whole 14x14 image, 7 rows of a 28x28 image (+ one
+//           halo row on either side whose expand values are recomputed), or three 7x7 images.
+//   x     = the tile's input pixels live in REGISTERS for the whole tile, as the MFMA A fragments of the expand GEMM:
+//           wave w owns the 16-pixel row tiles w and w + 8 (100 KiB of x at 14x14 = 49 registers per lane over 8 waves;
+//           the first version re-fetched them from L2 every round and spent 24 k of its 41 k cycles per round there).
+//   round = 32 expanded channels.  Step s of the software pipeline does, with ONE workgroup barrier at its end,
+//             E(s+1)  x (registers) x expand weights (LDS, staged by LDS-DMA) -> BN + PReLU -> E-image[(s+1)&1]
+//                     (row-padded: a zero pixel after every row, zero rows around / between images: no bounds checks)
+//             D(s)    3x3 depthwise + BN + PReLU, E-image[s&1] -> D-tile[s&1]  (a lane marches down a 7-row strip with
+//                     the 3x3 window in registers: 3 LDS reads per output instead of 9)
+//             P(s-1)  D-tile[(s-1)&1] x project weights (registers) -> the output tile, which stays in registers
+//                     (wave w owns 16 output channels of every pixel: no imbalance, no reduction)
+//           Waves 0-3 run E, P, D and waves 4-7 run D, E, P: the two waves of a SIMD are in different pipes most of
+//           the time (VALU under the partner's MFMAs) although every wave runs the same three phases.
+//   v_mfma_f32_16x16x4_f32: 196 pixels are 12.25 tiles of 16 rows (13: 6 % padding) but 6.1 of 32 (7: 14 %).
 //
-// Traffic per tile: x once from HBM (re-read per round from L2), y once; weights from L2.  The expanded tensor
-// (2 x G/C times the size of x) is neither written nor read: SURVEY 8(d)'s op-granular model counts it four times.
+// Traffic per tile: x once, y once, weights from L2.  The expanded tensor (2 G/C times the size of x) is neither written
+// nor read: SURVEY 8(d)'s op-granular model counts it four times.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -38,18 +42,18 @@ struct DwBlockArgs {
   const float* wp;    // project weights packed [G/4][C][4], then [C] scale, [C] bias
   int N, has_res;   // dense NHWC in / out: pixel stride C, image stride H*W*C; G = 2*C (every residual block)
 #ifdef FP_DWB_STAMPS
-  unsigned long long* stamps;   // lab builds only (tools/lab/dwblock_lab.hip): s_memtime per phase of every round
+  unsigned long long* stamps;   // lab builds only (tools/lab/dwblock_lab.hip): s_memtime per phase of every step
 #endif
 };
 
-// In-kernel phase stamps, compiled in by the lab harness only: [block < 8][wave][round < 8][6]
+// In-kernel phase stamps, compiled in by the lab harness only: [block < 8][wave < 8][step < 8][5]
 #ifdef FP_DWB_STAMPS
 #define DWB_STAMP(k)                                                                                        \
   do {                                                                                                      \
-    if (p.stamps && blockIdx.x < 8 && c < 8 && (threadIdx.x & 63) == 0) {                                   \
+    if (p.stamps && blockIdx.x < 8 && s < 8 && (threadIdx.x & 63) == 0) {                                   \
       unsigned long long tt_;                                                                               \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");                           \
-      p.stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + c) * 6 + (k)] = tt_;                            \
+      p.stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + s) * 5 + (k)] = tt_;                            \
     }                                                                                                       \
   } while (0)
 #else
@@ -59,7 +63,7 @@ struct DwBlockArgs {
 template <int C, int HW, int RB, int NIMG>
 struct DwbCfg {
   static_assert(NIMG == 1 || RB == HW, "several images per tile: whole images only");
-  static_assert(HW % RB == 0 && (C == 64 || C == 128), "");
+  static_assert(HW % RB == 0 && RB % 7 == 0 && (C == 64 || C == 128), "");
   static constexpr int G = 2 * C;                      // expanded channels (Depth_Wise `groups`)
   static constexpr int HALO = RB < HW ? 1 : 0;
   static constexpr int NBAND = HW / RB;
@@ -69,6 +73,7 @@ struct DwbCfg {
   static constexpr int EPX = NIMG * ER * HW;           // expanded pixels of a tile
   static constexpr int MTE = (EPX + 15) / 16;
   static constexpr int MTP = (OPX + 15) / 16;
+  static constexpr int NOWN = (MTE + 7) / 8;           // 16-pixel row tiles of x a wave owns (w, w + 8)
   static constexpr int ROWP = HW + 1;                  // slots per E-image row (one zero pad pixel)
   static constexpr int VR = NIMG > 1 ? NIMG * (HW + 1) - 1 : ER;   // rows of the E-image (zero rows between images)
   static constexpr int NSLOT = (VR + 2) * ROWP + 1;    // + zero row above / below, + the leading pad pixel
@@ -79,23 +84,23 @@ struct DwbCfg {
   static constexpr bool WE_LDS = C == 128;             // expand weights of a round through LDS (C = 64: registers)
   static constexpr int WL = WE_LDS ? C * KCH : 0;
   static constexpr int PL = 15 * KCH;
-  static constexpr int LDS_FLOATS = EB + DB + WL + 2 * PL;
-  static constexpr int NPW = C / 64;                   // 16-column tiles of the project output per wave
-  static constexpr int NT = C == 128 ? 1 : 2;          // 16-column tiles of the expand chunk per E unit
-  static constexpr int MSTR = NT == 1 ? 2 : 4;         // E units of a wave: m = m0 + MSTR*i
-  static constexpr int NU = (MTE + MSTR - 1) / MSTR;
-  static constexpr int KQ = C / 16;                    // float4 A fragments per unit
-  static constexpr int DIT = MTP;                      // depthwise iterations of a lane (16 pixels x 16 channel pairs each)
+  static constexpr int LDS_FLOATS = 2 * EB + 2 * DB + 2 * WL + 3 * PL;
+  static constexpr int KQ = C / 16;                    // float4 A fragments per row tile
+  static constexpr int NSTRIP = OPX / 7;               // depthwise strips (7 output rows of one column) per channel pair
+  static_assert(MTE <= 16 && NSTRIP <= 32 && OPX % 7 == 0, "");
+  // project: C = 128: wave w owns output columns 16w.. of every row tile; C = 64: columns 16(w & 3).., row tiles
+  // NPM(w >> 2) .. NPM(w >> 2) + NPM - 1
+  static constexpr int NPM = C == 128 ? MTP : (MTP + 1) / 2;
 };
 
 template <int C, int HW, int RB, int NIMG>
-__global__ __launch_bounds__(256, 2) void dwblock_kernel(DwBlockArgs p) {
+__global__ __launch_bounds__(512, 1) void dwblock_kernel(DwBlockArgs p) {
   using K = DwbCfg<C, HW, RB, NIMG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Eb = smem;
-  float* Db = Eb + K::EB;
-  float* Wl = Db + K::DB;
-  float* Pl = Wl + K::WL;
+  float* Eb = smem;                  // [2][EB]
+  float* Db = Eb + 2 * K::EB;        // [2][DB]
+  float* Wl = Db + 2 * K::DB;        // [2][WL]
+  float* Pl = Wl + 2 * K::WL;        // [3][PL]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,8 +110,7 @@ __global__ __launch_bounds__(256, 2) void dwblock_kernel(DwBlockArgs p) {
   const int r0 = (tile % K::NBAND) * RB;
   constexpr int G = K::G, R = G / K::KCH;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  // wave-uniform bases (SGPR pairs) + 32-bit lane offsets: 64-bit per-lane addresses for ~40 load sites, hoisted out of
-  // the round loop by LICM, cost more registers than the accumulators
+  // wave-uniform bases (SGPR pairs) + 32-bit lane offsets
   const float* xin = p.in + (long)img0 * (K::IPX * C);
   float* yout = p.out + (long)img0 * (K::IPX * C);
   const int nimg = min(NIMG, p.N - img0);              // images of this tile that exist
@@ -119,277 +123,288 @@ __global__ __launch_bounds__(256, 2) void dwblock_kernel(DwBlockArgs p) {
     ec = rem - er * HW;
   };
 
-  // lane ids as the round loop sees them: re-materialised (opaque to the optimiser) at the top of every round, so that
-  // the per-unit slot / offset arithmetic (~45 values) is recomputed there instead of being hoisted out of the loop
-  // and kept -- or spilled -- across it
+  // lane ids as the step loop sees them: re-materialised (opaque to the optimiser) at the top of every step, so that
+  // per-item slot / offset arithmetic is recomputed there instead of being hoisted out of the loop and kept live
   int lv = l15, qv = q, tv = tid;
 
   // ---- staging of a round's weights: LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, per-lane
-  // source address), no staging registers.  Wl is [C/4][32][4] floats = C/8 pieces of 1 KiB (two k4 rows each), Pl
-  // [15][32] floats = 1920 B (waves 0 and 1; lanes past the end are masked off by EXEC).
+  // source address), no staging registers.  Wl[c & 1] is [C/4][32][4] floats = C/8 pieces of 1 KiB (two k4 rows
+  // each), Pl[c % 3] is [15][32] floats = 1920 B (waves 0 and 1; lanes past the end are masked off by EXEC).
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   auto stage = [&](int c) {
     if (K::WE_LDS) {
 #pragma unroll
-      for (int jj = 0; jj < C / 8 / 4; ++jj) {
-        const int piece = jj * 4 + wave;                       // k4 rows 2*piece, 2*piece + 1
+      for (int jj = 0; jj < C / 8 / 8; ++jj) {
+        const int piece = jj * 8 + wave;                       // k4 rows 2*piece, 2*piece + 1
         const float* src = p.we + K::KCH * 4 * c + (((2 * piece + ((tv >> 5) & 1)) * G + (tv & 31)) * 4);
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Wl + piece * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Wl + (c & 1) * K::WL + piece * 256), 16, 0, 0);
       }
     }
     if (wave < 2) {
       const int t = tv;   // waves 0 and 1: t = tid
       if (t < 15 * 8) {
         const float* src = p.par + K::KCH * c + ((t >> 3) * G + 4 * (t & 7));
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Pl + (c & 1) * K::PL + wave * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Pl + (c % 3) * K::PL + wave * 256), 16, 0, 0);
       }
     }
   };
-  // expand weights of a round in registers (C = 64)
-  f32x4 breg[K::NT][K::KQ];
+  // expand weights of a round in registers (C = 64): both 16-column tiles, k = 16j + 4q + i
+  f32x4 breg[2][K::KQ];
   auto load_breg = [&](int c) {
     if (!K::WE_LDS) {
 #pragma unroll
-      for (int n = 0; n < K::NT; ++n)
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int j = 0; j < K::KQ; ++j)
-          breg[n][j] = *(const f32x4*)(p.we + K::KCH * 4 * c + ((q * G + l15) * 4 + (4 * j * G + n * 16) * 4));
+          breg[n][j] = *(const f32x4*)(p.we + K::KCH * 4 * c + ((qv * G + lv) * 4 + (4 * j * G + n * 16) * 4));
     }
   };
-  // project weights of a round: rows k = 32c + 16jj + 4q + i, this wave's columns
-  f32x4 pbw[K::NPW][2];
+  // project weights of a round: rows k = 32c + 16jj + 4q + i, this wave's 16 columns
+  const int pcol = C == 128 ? wave : (wave & 3);
+  const int pm0 = C == 128 ? 0 : (wave >> 2) * K::NPM;
+  f32x4 pbw[2];
   auto load_pbw = [&](int c) {
 #pragma unroll
-    for (int n = 0; n < K::NPW; ++n)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-        pbw[n][jj] = *(const f32x4*)(p.wp + 8 * C * 4 * c + ((q * C + wave * K::NPW * 16 + l15) * 4 + (4 * jj * C + n * 16) * 4));
+    for (int jj = 0; jj < 2; ++jj)
+      pbw[jj] = *(const f32x4*)(p.wp + 8 * C * 4 * c + ((qv * C + pcol * 16 + lv) * 4 + 4 * jj * C * 4));
   };
 
-  // ---- prologue: zero the E-image (pads stay zero for the whole tile), stage round 0 ----
-  stage(0);
-  load_breg(0);
-  for (int i = tid; i < K::EB / 4; i += 256) *(f32x4*)&Eb[i * 4] = z;
-
-  // A fragments of an E unit: rows = 16 E-pixels, k = 16j + 4q + i
-  const int em0 = K::NT == 1 ? (wave >> 1) : wave;
-  const int en0 = K::NT == 1 ? (wave & 1) : 0;
-  f32x4 afr[2][K::KQ];
-  auto load_a = [&](int m, int buf) {
-    const int e = min(16 * m + lv, K::EPX - 1);
+  // ---- prologue: x -> registers, zero both E-images (the pads stay zero for the whole tile), stage rounds 0 and 1 ----
+  f32x4 afr[K::NOWN][K::KQ];
+#pragma unroll
+  for (int t = 0; t < K::NOWN; ++t) {
+    const int m = wave + 8 * t;
+    const int e = min(16 * min(m, K::MTE - 1) + l15, K::EPX - 1);
     int ii, er, ec;
     e_decode(e, ii, er, ec);
     const int gr = min(max(r0 - K::HALO + er, 0), HW - 1);
-    const int aoff = (min(ii, nimg - 1) * K::IPX + gr * HW + ec) * C + 4 * qv;
+    const int aoff = (min(ii, nimg - 1) * K::IPX + gr * HW + ec) * C + 4 * q;
 #pragma unroll
-    for (int j = 0; j < K::KQ; ++j) afr[buf][j] = *(const f32x4*)(xin + (aoff + 16 * j));
-  };
+    for (int j = 0; j < K::KQ; ++j) afr[t][j] = *(const f32x4*)(xin + (aoff + 16 * j));
+  }
+  stage(0);
+  if (R > 1) stage(1);
+  load_breg(0);
+  for (int i = tid; i < 2 * K::EB / 4; i += 512) *(f32x4*)&Eb[i * 4] = z;
 
-  // output tile of this wave: [MTP][NPW] 16x16 accumulators
-  f32x4 pacc[K::MTP][K::NPW];
+  // output tile of this wave
+  f32x4 pacc[K::NPM];
 #pragma unroll
-  for (int m = 0; m < K::MTP; ++m)
-#pragma unroll
-    for (int n = 0; n < K::NPW; ++n) pacc[m][n] = z;
+  for (int m = 0; m < K::NPM; ++m) pacc[m] = z;
 
-  // P: D-tile (LDS) x pbw, two 16-row tiles at a time so that consecutive MFMAs never share an accumulator
-  auto project = [&]() {
+  // E-image slot (in floats, + column) of the 4 accumulator rows of each owned row tile, and their validity as a 0/1
+  // factor: computed once per tile (fp32 MFMAs and VALU instructions share the SIMD's vector ALU -- a wave's VALU work is
+  // NOT hidden under its partner's MFMAs (tools/lab/coexec_lab.hip: one VALU instruction per 32-cycle MFMA) -- so every
+  // instruction of the per-round epilogues counts)
+  int eslot[K::NOWN][4];
+  f32x2 evalid[K::NOWN][2];
 #pragma unroll
-    for (int m = 0; m < K::MTP; m += 2) {
-      f32x4 af[2][2];
+  for (int t = 0; t < K::NOWN; ++t)
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-          af[mm][jj] = *(const f32x4*)&Db[(16 * min(m + mm, K::MTP - 1) + l15) * K::LDD + 16 * jj + 4 * q];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int n = 0; n < K::NPW; ++n) {
-              if (m + mm < K::MTP) {
-                pacc[m + mm][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mm][jj][i], pbw[n][jj][i], pacc[m + mm][n], 0, 0, 0);
-                FP_MFMA_ORDER();
-              }
-            }
-      FP_SCHED_FENCE();   // hipcc otherwise hoists the LDS reads of every unrolled pair to the top (and spills)
+    for (int r = 0; r < 4; ++r) {
+      const int e = 16 * (wave + 8 * t) + 4 * q + r;
+      int ii, er, ec;
+      e_decode(min(e, K::EPX - 1), ii, er, ec);
+      const int vrow = NIMG > 1 ? ii * (HW + 1) + er : er;
+      const int slot = e < K::EPX ? (vrow + 1) * K::ROWP + ec + 1 : K::NSLOT;
+      eslot[t][r] = slot * K::KCH + l15;
+      evalid[t][r >> 1][r & 1] = (K::HALO == 0 || (unsigned)(r0 - 1 + er) < (unsigned)HW) ? 1.f : 0.f;
     }
-  };
 
-  __syncthreads();
-
-  for (int c = 0; c < R; ++c) {
-    const float* Pc = Pl + (c & 1) * K::PL;
-    asm volatile("" : "+v"(lv), "+v"(qv), "+v"(tv));
-    DWB_STAMP(0);
-    // ================= phase 1: matrix pipe =================
-    if (em0 < K::MTE) load_a(em0, 0);
-    FP_SCHED_FENCE();
-    if (c > 0) project();
-    DWB_STAMP(1);
-    {
-      float es[K::NT], eb[K::NT], esl[K::NT];
+  // E(c): x (registers) x expand weights -> BN + PReLU -> E-image[c & 1]
+  auto expand = [&](int c) {
+    float* Ec = Eb + (c & 1) * K::EB;
+    const float* Wc = Wl + (c & 1) * K::WL;
+    const float* Pc = Pl + (c % 3) * K::PL;
+    f32x2 es[2], eb[2], em[2];   // BN scale, BN bias, PReLU slope - 1 (both halves equal: packed math on row pairs)
 #pragma unroll
-      for (int n = 0; n < K::NT; ++n) {
-        const int ch = (en0 + n) * 16 + l15;
-        es[n] = Pc[ch];
-        eb[n] = Pc[K::KCH + ch];
-        esl[n] = Pc[2 * K::KCH + ch];
-      }
+    for (int n = 0; n < 2; ++n) {
+      const float a = Pc[n * 16 + lv], b = Pc[K::KCH + n * 16 + lv], sl = Pc[2 * K::KCH + n * 16 + lv] - 1.f;
+      es[n] = f32x2{a, a};
+      eb[n] = f32x2{b, b};
+      em[n] = f32x2{sl, sl};
+    }
 #pragma unroll
-      for (int u = 0; u < K::NU; ++u) {
-        const int m = em0 + K::MSTR * u;
-        if (m < K::MTE) {
-          if (u + 1 < K::NU && m + K::MSTR < K::MTE) load_a(m + K::MSTR, (u + 1) & 1);
-          f32x4 acc[2] = {z, z};
+    for (int t = 0; t < K::NOWN; ++t) {
+      const int m = wave + 8 * t;
+      if (m < K::MTE) {
+        f32x4 acc[2] = {z, z};
 #pragma unroll
-          for (int j = 0; j < K::KQ; ++j) {
-            if (K::NT == 1) {
-              const f32x4 b = *(const f32x4*)&Wl[((4 * j + q) * K::KCH + en0 * 16 + l15) * 4];
+        for (int j = 0; j < K::KQ; ++j) {
+          f32x4 b[2];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[u & 1][j][i], b[i], acc[j & 1], 0, 0, 0);
-                FP_MFMA_ORDER();
-              }
-            } else {
+          for (int n = 0; n < 2; ++n)
+            b[n] = K::WE_LDS ? *(const f32x4*)&Wc[((4 * j + qv) * K::KCH + n * 16 + lv) * 4] : breg[n][j];
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                  acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[u & 1][j][i], breg[n % K::NT][j][i], acc[n], 0, 0, 0);
-                  FP_MFMA_ORDER();
-                }
+            for (int n = 0; n < 2; ++n) {
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[t][j][i], b[n][i], acc[n], 0, 0, 0);
+              FP_MFMA_ORDER();
             }
-          }
-          if (K::NT == 1) acc[0] += acc[1];
-          // BN + PReLU -> E-image; rows outside the image are zeros (the depthwise pads the EXPANDED tensor)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = 16 * m + 4 * qv + r;
-            int ii, er, ec;
-            e_decode(min(e, K::EPX - 1), ii, er, ec);
-            const int vrow = NIMG > 1 ? ii * (HW + 1) + er : er;
-            int slot = (vrow + 1) * K::ROWP + ec + 1;
-            slot = e < K::EPX ? slot : K::NSLOT;
-            const bool valid = K::HALO == 0 || (unsigned)(r0 - 1 + er) < (unsigned)HW;
-#pragma unroll
-            for (int n = 0; n < K::NT; ++n) {
-              float v = acc[n][r] * es[n] + eb[n];
-              v = v > 0.f ? v : v * esl[n];
-              Eb[slot * K::KCH + (en0 + n) * 16 + lv] = valid ? v : 0.f;
-            }
-          }
         }
+        // v = acc*s + b; PReLU(v) = v + (slope - 1)*min(v, 0); rows outside the image are zeros (the depthwise pads
+        // the EXPANDED tensor); rows past EPX go to slot NSLOT
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x2 v = f32x2{acc[n][2 * h], acc[n][2 * h + 1]} * es[n] + eb[n];
+            const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
+            v = neg * em[n] + v;
+            if (K::HALO) v *= evalid[t][h];
+            Ec[eslot[t][2 * h] + n * 16] = v[0];
+            Ec[eslot[t][2 * h + 1] + n * 16] = v[1];
+          }
         FP_SCHED_FENCE();
       }
     }
-    DWB_STAMP(2);
-    __syncthreads();
-    DWB_STAMP(3);
+  };
 
-    // ================= phase 2: VALU =================
-    const bool more = c + 1 < R;
-    if (more) {
-      stage(c + 1);   // Wl: E(c) has finished with it (barrier above); Pl: the other buffer; drained by the barrier below
-      load_breg(c + 1);
-    }
-    load_pbw(c);
-    {
-      // lane = 2 channels (c2) of pixel it*16 + pxo: with 4 channels per lane the taps alone are 48 registers, and this
-      // phase also carries the whole output tile (104) and the next round's project weights
-      const int c2 = tv & 15, pxo = tv >> 4;
+  // D(c): 3x3 depthwise + BN + PReLU, E-image[c & 1] -> D-tile[c & 1].  Lane = (channel pair c2, strip): a strip is 7
+  // consecutive output rows of one column; the window slides down with 3 new LDS reads per output.
+  auto depthwise = [&](int c) {
+    const float* Ec = Eb + (c & 1) * K::EB;
+    float* Dc = Db + (c & 1) * K::DB;
+    const float* Pc = Pl + (c % 3) * K::PL;
+    const int c2 = tv & 15, strip = tv >> 4;
+    if (strip < K::NSTRIP) {
+      int vrow0, col, o0;
+      if (K::HALO) {                 // band of a larger image: strip = column, E row 0 is the halo row above
+        col = strip; vrow0 = 1; o0 = col;
+      } else if (NIMG > 1) {         // several small images: strip = (image, column)
+        const int im = strip / HW;
+        col = strip - im * HW; vrow0 = im * (HW + 1); o0 = im * K::IPX + col;
+      } else {                       // one image: strip = (7-row part, column)
+        const int part = strip / HW;
+        col = strip - part * HW; vrow0 = 7 * part; o0 = vrow0 * HW + col;
+      }
       f32x2 tap[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) tap[t] = *(const f32x2*)&Pc[(3 + t) * K::KCH + 2 * c2];
       const f32x2 dsc = *(const f32x2*)&Pc[12 * K::KCH + 2 * c2];
       const f32x2 dbi = *(const f32x2*)&Pc[13 * K::KCH + 2 * c2];
-      const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2];
+      const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2] - f32x2{1.f, 1.f};   // PReLU slope - 1
+      // window rows: w0 = row r-1, w1 = row r, w2 = row r+1 (columns col-1 .. col+1)
+      const float* base = &Ec[((vrow0 + 1) * K::ROWP + col + 1) * K::KCH + 2 * c2];   // E pixel (vrow0, col)
+      f32x2 w0[3], w1[3], w2[3];
 #pragma unroll
-      for (int it = 0; it < K::DIT; ++it) {
-        const int o = it * 16 + pxo;
-        const int oc = min(o, K::OPX - 1);
-        const int ii = NIMG > 1 ? oc / K::IPX : 0;
-        const int rem = oc - ii * K::IPX;
-        const int orow = rem / HW, ocol = rem - orow * HW;
-        const int vrow = (NIMG > 1 ? ii * (HW + 1) : 0) + orow + K::HALO;
-        const float* ctr = &Eb[((vrow + 1) * K::ROWP + ocol + 1) * K::KCH + 2 * c2];
-        f32x2 s = {0.f, 0.f};
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-            s += *(const f32x2*)(ctr + ((dy - 1) * K::ROWP + (dx - 1)) * K::KCH) * tap[dy * 3 + dx];
-        f32x2 v = s * dsc + dbi;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * dsl[e];
-        *(f32x2*)&Db[o * K::LDD + 2 * c2] = v;
-        FP_SCHED_FENCE();
+      for (int dx = 0; dx < 3; ++dx) {
+        w0[dx] = *(const f32x2*)(base + (-K::ROWP + dx - 1) * K::KCH);
+        w1[dx] = *(const f32x2*)(base + (dx - 1) * K::KCH);
       }
-    }
-    DWB_STAMP(4);
-    __syncthreads();
-    DWB_STAMP(5);
-  }
-  project();
-
-  // ---- epilogue: BN affine (+ x), straight from the accumulators: rows 4q + r of 16-row tile m, column l15 ----
-  const float* pscale = p.wp + G * C;
-  const float* pbias = pscale + C;
-  float ps[K::NPW], pb[K::NPW];
 #pragma unroll
-  for (int n = 0; n < K::NPW; ++n) {
-    ps[n] = pscale[(wave * K::NPW + n) * 16 + l15];
-    pb[n] = pbias[(wave * K::NPW + n) * 16 + l15];
-  }
-  constexpr int HALF = (K::MTP + 1) / 2;
+      for (int r = 0; r < 7; ++r) {
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    // every residual load of this half first, then its stores (vmcnt is one in-order counter for loads and stores)
-    f32x4 rv[HALF][K::NPW];
-    int off[HALF][4];   // relative to image img0, -1 = not stored
+        for (int dx = 0; dx < 3; ++dx) w2[dx] = *(const f32x2*)(base + ((r + 1) * K::ROWP + dx - 1) * K::KCH);
+        f32x2 sacc = {0.f, 0.f};
 #pragma unroll
-    for (int mi = 0; mi < HALF; ++mi) {
-      const int m = hh * HALF + mi;
+        for (int dx = 0; dx < 3; ++dx) sacc += w0[dx] * tap[dx];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * m + 4 * q + r;
-        const int oc = min(o, K::OPX - 1);
-        const int ii = NIMG > 1 ? oc / K::IPX : 0;
-        const int rem = oc - ii * K::IPX;
-        const bool ok = m < K::MTP && o < K::OPX && ii < nimg;
-        const int po = (min(ii, nimg - 1) * K::IPX + r0 * HW + rem) * C + wave * K::NPW * 16 + l15;
-        off[mi][r] = ok ? po : -1;
-        if (p.has_res) {
+        for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
 #pragma unroll
-          for (int n = 0; n < K::NPW; ++n) rv[mi][n][r] = m < K::MTP ? xin[po + n * 16] : 0.f;
+        for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+        f32x2 v = sacc * dsc + dbi;
+        const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
+        v = neg * dsl + v;                                     // PReLU(v) = v + (slope - 1)*min(v, 0)
+        *(f32x2*)&Dc[(o0 + r * HW) * K::LDD + 2 * c2] = v;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          w0[dx] = w1[dx];
+          w1[dx] = w2[dx];
         }
       }
     }
+  };
+
+  // P(c): D-tile[c & 1] x pbw, two 16-row tiles at a time so that consecutive MFMAs never share an accumulator
+  auto project = [&](int c) {
+    const float* Dc = Db + (c & 1) * K::DB;
 #pragma unroll
-    for (int mi = 0; mi < HALF; ++mi) {
-      const int m = hh * HALF + mi;
-      if (m < K::MTP) {
+    for (int m = 0; m < K::NPM; m += 2) {
+      f32x4 af[2][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+      for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-          for (int n = 0; n < K::NPW; ++n) {
-            float v = pacc[m][n][r] * ps[n] + pb[n];
-            if (p.has_res) v += rv[mi][n][r];
-            if (off[mi][r] >= 0) yout[off[mi][r] + n * 16] = v;
+        for (int jj = 0; jj < 2; ++jj)
+          af[mm][jj] = *(const f32x4*)&Dc[(16 * min(pm0 + m + mm, K::MTP - 1) + lv) * K::LDD + 16 * jj + 4 * qv];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            if (m + mm < K::NPM) {
+              pacc[m + mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mm][jj][i], pbw[jj][i], pacc[m + mm], 0, 0, 0);
+              FP_MFMA_ORDER();
+            }
           }
-      }
+      FP_SCHED_FENCE();   // hipcc otherwise hoists the LDS reads of every unrolled pair to the top (and spills)
+    }
+  };
+
+  __syncthreads();          // E-images zeroed, Wl[0..1] / Pl[0..1] landed (the barrier drains the LDS-DMA)
+  expand(0);
+  load_breg(1 < R ? 1 : 0);
+  load_pbw(0);
+  __syncthreads();
+
+  const bool early = wave < 4;   // waves 0-3: E, P, D; waves 4-7: D, E, P
+  for (int s = 0; s < R; ++s) {
+    asm volatile("" : "+v"(lv), "+v"(qv), "+v"(tv));
+    DWB_STAMP(0);
+    if (s + 2 < R) stage(s + 2);   // Wl[s & 1]: E(s) finished with it in the previous step; Pl[(s + 2) % 3]: free
+    if (!early) depthwise(s);
+    DWB_STAMP(1);
+    if (s + 1 < R) {
+      expand(s + 1);
+      if (s + 2 < R) load_breg(s + 2);
+    }
+    DWB_STAMP(2);
+    if (s > 0) {
+      project(s - 1);
+      load_pbw(s);
+    }
+    DWB_STAMP(3);
+    if (early) depthwise(s);
+    DWB_STAMP(4);
+    __syncthreads();
+  }
+  project(R - 1);
+
+  // ---- epilogue: BN affine (+ x), straight from the accumulators: rows 4q + r of 16-row tile m, column l15 ----
+  const float ps = (p.wp + G * C)[pcol * 16 + l15];
+  const float pb = (p.wp + G * C + C)[pcol * 16 + l15];
+  f32x4 rv[K::NPM];
+  int off[K::NPM][4];   // relative to image img0, -1 = not stored
+#pragma unroll
+  for (int mi = 0; mi < K::NPM; ++mi) {   // every residual load first, then the stores (vmcnt counts both, in order)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * (pm0 + mi) + 4 * q + r;
+      const int oc = min(o, K::OPX - 1);
+      const int ii = NIMG > 1 ? oc / K::IPX : 0;
+      const int rem = oc - ii * K::IPX;
+      const bool ok = pm0 + mi < K::MTP && o < K::OPX && ii < nimg;
+      const int po = (min(ii, nimg - 1) * K::IPX + r0 * HW + rem) * C + pcol * 16 + l15;
+      off[mi][r] = ok ? po : -1;
+      rv[mi][r] = p.has_res ? xin[po] : 0.f;
     }
   }
+#pragma unroll
+  for (int mi = 0; mi < K::NPM; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = pacc[mi][r] * ps + pb + rv[mi][r];
+      if (off[mi][r] >= 0) yout[off[mi][r]] = v;
+    }
 }
 
 template <int C, int HW, int RB, int NIMG>
 int launch_variant(const DwBlockArgs& a, hipStream_t s) {
   using K = DwbCfg<C, HW, RB, NIMG>;
-  static_assert(K::LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+  static_assert(K::LDS_FLOATS * 4 <= 160 * 1024, "one workgroup per CU");
   constexpr int lds = K::LDS_FLOATS * 4;
   const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_kernel<C, HW, RB, NIMG>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -398,7 +413,7 @@ int launch_variant(const DwBlockArgs& a, hipStream_t s) {
     return FP_ERR_LAUNCH;
   }
   const int tiles = fp_ceil_div(a.N, NIMG) * K::NBAND;
-  hipLaunchKernelGGL((dwblock_kernel<C, HW, RB, NIMG>), dim3(tiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dwblock_kernel<C, HW, RB, NIMG>), dim3(tiles), dim3(512), lds, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
@@ -426,6 +441,7 @@ bool fp_dwblock_supported(const fp_op& op) {
 int fp_launch_dwblock(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
   if (!fp_dwblock_supported(op)) return FP_ERR_UNSUPPORTED;
   DwBlockArgs a;
+  memset(&a, 0, sizeof(a));
   a.in = arena + op.in_off;
   a.out = arena + op.out_off;
   a.we = weights + op.w_off;
@@ -434,6 +450,6 @@ int fp_launch_dwblock(const fp_op& op, const float* weights, float* arena, hipSt
   a.N = op.N;
   a.has_res = op.res_mode == FP_RES_ADD_AFTER_ACT;
   if (op.Cin == 128 && op.H == 14) return launch_variant<128, 14, 14, 1>(a, s);
-  if (op.Cin == 128 && op.H == 7) return launch_variant<128, 7, 7, 2>(a, s);
+  if (op.Cin == 128 && op.H == 7) return launch_variant<128, 7, 7, 3>(a, s);
   return launch_variant<64, 28, 7, 1>(a, s);
 }

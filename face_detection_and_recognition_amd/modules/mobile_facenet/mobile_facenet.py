@@ -84,15 +84,35 @@ class Depth_Wise(_NoCompute):
         self.residual = residual
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
-    FUSE_BLOCK = True       # whole block as FP_OP_DWBLOCK where csrc/dwblock.hip has the shape (stride-1 blocks)
-    FUSE_BLOCK_MIN_N = 64   # below this batch capacity a tile-per-workgroup kernel cannot fill the chip
+    # Whole block as ONE kernel (FP_OP_DWBLOCK, csrc/dwblock.hip) on the map sizes in BLOCK_SHAPES; None = block_policy
+    # of the batch the plan will run on.  Tests pin it to a tuple.
+    BLOCK_SHAPES = None
+
+    @staticmethod
+    def block_policy(n):
+        """Map sizes (14, 7; 28 never) on which the whole-block kernel beats the two-launch form at batch n, from
+        the measured costs on MI355X (profiles/r03_mfn_probe.log, tools/lab/dwblock_lab): the block kernel runs one
+        tile per CU at a time (14x14: one image, 84 us per round of 256 tiles; 7x7: three images, 66 us per round), the
+        pair scales with n (14x14: 0.348 us per image; 7x7: 33 us + 0.094 us per image).  At the bench's ~528 faces the
+        14x14 blocks would need a third, nearly empty round (239 us against 184), so only the 7x7 blocks take it."""
+        shapes = []
+        if n >= 256 and -(-n // 256) * 84.0 < 0.348 * n:
+            shapes.append(14)
+        if n >= 192 and -(-(-(-n // 3)) // 256) * 66.0 < 33.0 + 0.094 * n:
+            shapes.append(7)
+        return tuple(shapes)
 
     def emit(self, pb, x, expanded=None):
         """expanded: the output of self.conv when the caller has already produced it (fused into the previous
         depthwise Conv_block, see MobileFaceNet._emit); x is then only the residual source."""
         dw, pj, ex = self.conv_dw, self.project, self.conv
-        if (Depth_Wise.FUSE and Depth_Wise.FUSE_BLOCK and expanded is None and pb.N >= Depth_Wise.FUSE_BLOCK_MIN_N and
-                dw.k == 3 and dw.p == 1 and pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
+        shapes = Depth_Wise.BLOCK_SHAPES
+        if shapes is None:
+            shapes = getattr(pb, "dwblock_shapes", None)
+        if shapes is None:
+            shapes = Depth_Wise.block_policy(pb.N)
+        if (Depth_Wise.FUSE and expanded is None and x.H in shapes and dw.k == 3 and dw.p == 1 and
+                pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
             y = pb.new_buf(x.H, x.W, pj.out_c)
             pb.dwblock(x, npy(ex.conv.weight), _affine(ex.bn), npy(ex.prelu.weight),
                        npy(dw.conv.weight), _affine(dw.bn), npy(dw.prelu.weight),
@@ -172,9 +192,11 @@ class MobileFaceNet(nn.Module):
         self._plans.clear()
         return out
 
-    def _emit(self, N, H=112, W=112):
-        """Emit the op list for batch N (host only, no GPU needed)."""
+    def _emit(self, N, H=112, W=112, block_shapes=None):
+        """Emit the op list for batch N (host only, no GPU needed).  block_shapes: map sizes whose stride-1 Depth_Wise
+        blocks become FP_OP_DWBLOCK (None: Depth_Wise.block_policy(N))."""
         pb = PlanBuilder(N)
+        pb.dwblock_shapes = block_shapes
         inp = pb.new_buf(H, W, 3)
         x = self.conv1.emit(pb, inp.view())
         c2, c23 = self.conv2_dw, self.conv_23
@@ -209,18 +231,24 @@ class MobileFaceNet(nn.Module):
         pb.l2norm(z.view(0, E), o.view(0, E))
         return pb, inp, o
 
-    def _build(self, N, cache=None):
+    def _build(self, N, cache=None, block_shapes=None):
         E = self.embedding_size
-        pb, inp, o = self._emit(N)
+        pb, inp, o = self._emit(N, block_shapes=block_shapes)
         plan = CompiledPlan(pb, self._device(), cache)
         plan.input = plan.buf_tensor(inp, N)
         plan.out = plan.buf_tensor(o, N).view(N, -1)[:, :E]
         return plan
 
-    def plan_for(self, N):
+    def plan_for(self, N, n_run=None):
+        """The plan with batch capacity N.  n_run: the batch it is about to run on (a prefix of its capacity,
+        CompiledPlan.run(n)); which blocks use the whole-block kernel follows n_run (Depth_Wise.block_policy), so a
+        capacity can have up to four plans (the 14x14 / 7x7 choices), each with its own arena."""
         if self._device().type != "cuda":
             raise L.FacepathError("MobileFaceNet runs only on a HIP device (model.to('cuda')); there is no CPU path")
-        return self._plans.get(N, lambda cache: self._build(N, cache))
+        shapes = Depth_Wise.BLOCK_SHAPES if Depth_Wise.BLOCK_SHAPES is not None else \
+            Depth_Wise.block_policy(N if n_run is None else n_run)
+        shapes = tuple(shapes)
+        return self._plans.get((N, shapes, Depth_Wise.FUSE), lambda cache: self._build(N, cache, block_shapes=shapes))
 
     def forward(self, x):
         b = x.shape[0]

@@ -81,7 +81,7 @@ class FacePipeline:
         n_pad = (n_faces + self.bucket - 1) // self.bucket * self.bucket
         cap = max(getattr(self, "_emb_cap", 0), (n_pad + 255) // 256 * 256)
         self._emb_cap = cap
-        plan = self.emb.plan_for(cap)
+        plan = self.emb.plan_for(cap, n_run=n_pad)
         self.emb_plan, self.emb_n_pad = plan, n_pad
         crops_to_input(frames, items, n_faces, plan.input, self.lut)
         plan.run(n=n_pad)

@@ -67,8 +67,14 @@ def read_and_preprocess_img(img_path: str, in_size=(160, 160), dct_method: str =
     return preprocess_tf_standardize(t, in_size)[0]
 
 
-def embed_images(model, paths, batch_size=32):
-    """Decode on the host, then crop(whole image)+resize+normalise and embed on device, batch by batch."""
+def embed_images(model, paths, batch_size=32, preprocess="mobile_facenet"):
+    """Decode on the host, then resize + normalise and embed on device, batch by batch.  preprocess:
+    "mobile_facenet" = cv2-style resize of the whole image to 112x112, (x - 127.5) / 127.5, BGR
+    (fde/modules/mobile_facenet/utils.py:13-17); "tf_standardize" = the reference filter's own TF preprocess
+    (filter_faces_using_reference.py:60-68: RGB, [0,1], bilinear resize, per-image standardisation) at the network's
+    112x112 input size."""
+    if preprocess not in ("mobile_facenet", "tf_standardize"):
+        raise ValueError(f"unknown preprocess {preprocess!r}")
     dev = model._device()
     lut = mfn_lut(dev)
     feats = []
@@ -77,6 +83,11 @@ def embed_images(model, paths, batch_size=32):
         plan = model.plan_for(len(chunk))
         for j, pth in enumerate(chunk):          # images differ in size: one resize launch per image
             img = torch.from_numpy(read_image_bgr(pth)).to(dev).unsqueeze(0)
+            if preprocess == "tf_standardize":
+                rgb = img.flip(-1).contiguous()
+                plan.input[j, ..., :3].copy_(preprocess_tf_standardize(rgb, (112, 112))[0])
+                plan.input[j, ..., 3:].zero_()
+                continue
             h, w = img.shape[1:3]
             item = torch.tensor([[0, 0, 0, w, h, 0, 0, 112, 112]], dtype=torch.int32, device=dev)
             crops_to_input(img, item, 1, plan.input[j:j + 1], lut)
@@ -85,10 +96,11 @@ def embed_images(model, paths, batch_size=32):
     return torch.cat(feats) if feats else torch.zeros((0, model.embedding_size), device=dev)
 
 
-def get_ref_mean_vec_and_thres_from_imgs(model, ref_class_path: str, max_ref_img_count: int = 32) -> Tuple[np.ndarray, np.ndarray]:
+def get_ref_mean_vec_and_thres_from_imgs(model, ref_class_path: str, max_ref_img_count: int = 32,
+                                         preprocess: str = "mobile_facenet") -> Tuple[np.ndarray, np.ndarray]:
     """:71-100: mean vector of the first <= max_ref_img_count reference embeddings and the max L2 distance to it."""
     X_imgs = glob.glob(ref_class_path + "/*.jpg")[:max_ref_img_count]
-    feats = embed_images(model, X_imgs, batch_size=1 if len(X_imgs) < 2 else min(32, len(X_imgs)))
+    feats = embed_images(model, X_imgs, batch_size=1 if len(X_imgs) < 2 else min(32, len(X_imgs)), preprocess=preprocess)
     mean, thres = S.l2_mean_thres(feats)
     print(f"number of samples considered for reference={len(X_imgs)}", f"ref mean shape={tuple(mean.shape)}")
     print("max dist from mean in the reference batch: ", float(thres))
@@ -107,6 +119,9 @@ def get_parsed_args(argv=None):
     parser.add_argument('-r', '--ref_img_per_class', type=int, default=32)
     parser.add_argument('--metric', choices=["l2_mean", "cosine"], default="l2_mean")
     parser.add_argument('--tau', type=float, default=0.3)
+    parser.add_argument('--preprocess', choices=["mobile_facenet", "tf_standardize"], default="mobile_facenet",
+                        help='mobile_facenet: (x - 127.5)/127.5 BGR at 112x112 (mobile_facenet/utils.py:13-17); tf_standardize: '
+                             'the reference filter\'s read_and_preprocess_img (:60-68) at 112x112. (default: %(default)s)')
     parser.add_argument('-d', '--device', default="cuda")
     return parser.parse_args(argv)
 
@@ -117,12 +132,14 @@ def filter_class(model, ref_class_path, unfiltered_class_path, clean_dir, unclea
     name = unfiltered_class_path.split('/')[-1]
     os.makedirs(os.path.join(clean_dir, name), exist_ok=True)
     os.makedirs(os.path.join(unclean_dir, name), exist_ok=True)
-    feats = embed_images(model, X_imgs, args.batch_size)
+    pre = getattr(args, "preprocess", "mobile_facenet")
+    feats = embed_images(model, X_imgs, args.batch_size, preprocess=pre)
     if args.metric == "l2_mean":
-        mean, thres = get_ref_mean_vec_and_thres_from_imgs(model, ref_class_path, args.ref_img_per_class)
+        mean, thres = get_ref_mean_vec_and_thres_from_imgs(model, ref_class_path, args.ref_img_per_class, preprocess=pre)
         _, keep = S.l2_filter(feats, mean, thres)
     else:
-        refs = embed_images(model, glob.glob(ref_class_path + "/*.jpg")[:args.ref_img_per_class], args.batch_size)
+        refs = embed_images(model, glob.glob(ref_class_path + "/*.jpg")[:args.ref_img_per_class], args.batch_size,
+                            preprocess=pre)
         _, _, keep = S.cosine_filter(feats, refs, args.tau)
     keep = keep.cpu().numpy()
     for pth, k in zip(X_imgs, keep):

@@ -180,6 +180,22 @@ def test_filter_faces_using_reference_cli(dev, tmp_path):
     for p, k, mg in zip(paths, keep, margin):
         if mg:
             assert (os.path.basename(p) in got_clean) == bool(k)
+    # --preprocess tf_standardize: the reference filter's own read_and_preprocess_img (:60-68) in front of the network
+    # (at its 112x112 input), end to end through the CLI and against the oracle's restatement of that preprocess
+    F.main(["--ud", str(tmp_path / "unf"), "--rd", str(tmp_path / "ref"), "--td", str(tmp_path / "out_tf"), "-m", wpath,
+            "-b", "4", "--preprocess", "tf_standardize", "-d", "hip:0"])
+    assert sum(len(os.listdir(tmp_path / "out_tf" / d / "class_a")) for d in ("clean", "unclean")) == 9
+    e_tf = F.embed_images(netd, paths[:3], 4, preprocess="tf_standardize").cpu().numpy()
+
+    def emb_ref_tf(p):
+        rgb = np.ascontiguousarray(F.read_image_bgr(p)[..., ::-1])
+        x = image_ref.read_and_preprocess_rgb(rgb, (112, 112)).astype(np.float32)
+        with torch.no_grad():
+            return mobilefacenet_ref.forward(sd, torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))).unsqueeze(0))[0].numpy()
+    assert np.abs(e_tf - np.stack([emb_ref_tf(p) for p in paths[:3]])).max() < 1e-4
+    assert np.abs(e_tf - e_hip[:3]).max() > 1e-3          # it IS a different preprocess
+    with pytest.raises(ValueError):
+        F.embed_images(netd, paths[:1], 1, preprocess="nope")
     with pytest.raises(Exception):
         os.makedirs(tmp_path / "ref" / "class_c")
         F.main(["--ud", str(tmp_path / "unf"), "--rd", str(tmp_path / "ref"), "--td", str(tmp_path / "o2"), "-m", wpath])

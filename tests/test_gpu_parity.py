@@ -369,11 +369,11 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
     x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
     pb = PlanBuilder(n)
     inp = pb.new_buf(hw, hw, cin)
-    Depth_Wise.FUSE_BLOCK = False      # the two-launch form (still what stride-2 blocks and small batches run)
+    Depth_Wise.BLOCK_SHAPES = ()       # the two-launch form (what stride-2 blocks, 28x28 blocks and most batches run)
     try:
         y = blk.emit(pb, inp.view())
     finally:
-        Depth_Wise.FUSE_BLOCK = True
+        Depth_Wise.BLOCK_SHAPES = None
     plan = CompiledPlan(pb, dev)
     names = [plan.kernel_name(i) for i in range(plan.n_ops)]
     # 28 x 28 / 56 x 56 shapes: the wave-private kernel (projection weights resident in LDS); 14 x 14: the workgroup one
@@ -398,7 +398,7 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
     (128, 14, False, 3),    # no shortcut, fewer tiles than CUs
     (64, 28, True, 37),     # four 7-row bands per image, halo rows recomputed, zero rows at the image border
     (64, 28, False, 2),
-    (128, 7, True, 65),     # two images per tile, odd batch: the last tile holds one image
+    (128, 7, True, 65),     # three images per tile; 65 = 21 * 3 + 2: the last tile holds two images
     (128, 7, False, 4),
     (128, 14, True, 530),   # bench-like batch: more tiles than resident workgroups
 ])
@@ -414,12 +414,11 @@ def test_dwblock_whole_depth_wise_vs_oracle(dev, cin, hw, residual, n):
     x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
     pb = PlanBuilder(n)
     inp = pb.new_buf(hw, hw, cin)
-    old = Depth_Wise.FUSE_BLOCK_MIN_N
-    Depth_Wise.FUSE_BLOCK_MIN_N = 1
+    Depth_Wise.BLOCK_SHAPES = (hw,)
     try:
         y = blk.emit(pb, inp.view())
     finally:
-        Depth_Wise.FUSE_BLOCK_MIN_N = old
+        Depth_Wise.BLOCK_SHAPES = None
     plan = CompiledPlan(pb, dev)
     assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_kernel"), [plan.kernel_name(i) for i in range(plan.n_ops)]
     t = plan.buf_tensor(inp, n)
@@ -447,7 +446,11 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
     net = net.to(dev)
     x = torch.from_numpy(g["x"]).to(dev)
     n = x.shape[0]
-    plan = net.plan_for(64)
+    Depth_Wise.BLOCK_SHAPES = (28, 14, 7)
+    try:
+        plan = net.plan_for(64)
+    finally:
+        Depth_Wise.BLOCK_SHAPES = None
     kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
     assert kinds.count(L.OP_DWBLOCK) == 12
     plan.input[:n, ..., :3].copy_(x.permute(0, 2, 3, 1))
@@ -607,15 +610,26 @@ def test_resize_normalize_vs_oracle(dev, lib):
 
 
 def test_similarity_vs_golden_and_oracle(dev):
+    """fp_l2_mean_thres / fp_l2_filter against what the reference's own get_ref_mean_vec_and_thres_from_imgs and main()
+    produced (tests/golden/similarity.npz, three classes; sff/filter_faces_using_reference.py:71-100,183-197): mean to
+    1e-6, threshold to 1e-6 relative, the clean / unclean decision of every image exact except where the reference's
+    distance is within 1e-4 of its threshold -- and the reference images that reappear among the unfiltered ones
+    (class 2, distance == threshold for the farthest) must be kept."""
     g = golden("similarity")
-    ref = torch.from_numpy(g["ref"]).to(dev)
-    mean, thres = S.l2_mean_thres(ref)
-    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=0, atol=1e-6)
-    assert abs(float(thres) - float(g["thres"])) < 1e-4
-    dist, keep = S.l2_filter(torch.from_numpy(g["E"]).to(dev), mean, thres)
-    np.testing.assert_allclose(dist.cpu().numpy(), g["dist"], rtol=0, atol=1e-4)
-    margin = np.abs(g["dist"] - float(g["thres"])) > 1e-3
-    np.testing.assert_array_equal(keep.cpu().numpy()[margin], g["keep"][margin])
+    for c in range(3):
+        ref = torch.from_numpy(g[f"c{c}_ref"]).to(dev)
+        mean, thres = S.l2_mean_thres(ref)
+        np.testing.assert_allclose(mean.cpu().numpy(), g[f"c{c}_mean"], rtol=0, atol=1e-6)
+        assert abs(float(thres) - float(g[f"c{c}_thres"])) < 1e-6 * float(g[f"c{c}_thres"]) + 1e-6
+        E = g[f"c{c}_E"]
+        dist, keep = S.l2_filter(torch.from_numpy(E).to(dev), mean, thres)
+        dref = np.array([np.linalg.norm(e - g[f"c{c}_mean"]) for e in E])
+        np.testing.assert_allclose(dist.cpu().numpy(), dref, rtol=0, atol=1e-4)
+        sure = np.abs(dref - float(g[f"c{c}_thres"])) > 1e-4
+        assert sure.sum() >= len(sure) - 1
+        np.testing.assert_array_equal(keep.cpu().numpy()[sure], g[f"c{c}_keep"][sure])
+        if c == 2:
+            assert keep.cpu().numpy()[:6].all()
     # cosine vs the reference formula (pairwise) and the oracle
     best, arg, keepc = S.cosine_filter(torch.from_numpy(g["cos_a"]).to(dev), torch.from_numpy(g["cos_b"]).to(dev), 0.1)
     sim = 1.0 - g["cos_dist"]

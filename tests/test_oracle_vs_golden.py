@@ -63,11 +63,24 @@ def test_postprocess_matches_reference():
 
 
 def test_similarity_matches_reference_arithmetic():
+    """S1/S2 against outputs of the reference's OWN functions: tests/golden/similarity.npz holds, for three classes, what
+    get_ref_mean_vec_and_thres_from_imgs (sff/filter_faces_using_reference.py:71-100) returned and what main()
+    (:183-197) decided per unfiltered image, run on a tensorflow stub (tools/gen_golden.py gen_similarity)."""
     g = golden("similarity")
-    mean, thres = similarity_ref.ref_mean_and_thres(g["ref"])
-    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=1e-7)
-    assert abs(float(thres) - float(g["thres"])) < 1e-5
-    dist, keep = similarity_ref.l2_filter(g["E"], mean, thres)
+    assert len(g["classes"]) == 3
+    for c in range(3):
+        mean, thres = similarity_ref.ref_mean_and_thres(g[f"c{c}_ref"])
+        np.testing.assert_array_equal(mean, g[f"c{c}_mean"])                 # same numpy calls as the reference: exact
+        assert np.float32(thres) == g[f"c{c}_thres"]
+        dist, keep = similarity_ref.l2_filter(g[f"c{c}_E"], mean, thres)
+        np.testing.assert_array_equal(keep, g[f"c{c}_keep"])
+        assert 0 < keep.sum() < len(keep)
+    # class 2's first six unfiltered images ARE reference images; the farthest one sits exactly on the threshold (<=)
+    d2 = np.array([np.linalg.norm(e - g["c2_mean"]) for e in g["c2_E"][:6]])
+    assert g["c2_keep"][:6].all() and (d2 == g["c2_thres"]).any()
+    assert g["c0_ref"].shape[0] == 32 and g["c1_ref"].shape[0] == 5         # 40 reference files: first 32 used; 5: all
+    # legacy keys (class 0) + S3's cosine formula
+    dist, keep = similarity_ref.l2_filter(g["E"], g["mean"], g["thres"])
     np.testing.assert_allclose(dist, g["dist"], rtol=0, atol=1e-5)
     np.testing.assert_array_equal(keep, g["keep"])
     best, arg, _, S = similarity_ref.cosine_filter(g["cos_a"], g["cos_b"], 0.0)

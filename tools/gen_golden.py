@@ -146,23 +146,78 @@ def gen_utils(ns):
 
 
 def gen_similarity():
-    """S1/S2 arithmetic: filter_faces_using_reference.py cannot be imported (top-level tensorflow import,
-    SURVEY 8c); its ten lines of numpy are run here verbatim-in-spirit on random features through numpy
-    itself, plus the one pinned value the reference's own test holds (thres for its 128-d fixture needs the
-    FaceNet weights and is therefore not reproducible offline)."""
+    """S1/S2 from the reference's OWN code: similar_face_filtering/filter_faces_using_reference.py is imported on a
+    tensorflow stub (tools/ref_harness.install_tensorflow_stub: images are paths, the "model" returns seeded feature
+    rows keyed by file name) and both get_ref_mean_vec_and_thres_from_imgs (:71-100) and main() (:127-199) run on a
+    temporary tree of three classes: a full one (40 reference files, 32 used), a short one (5) and one whose unfiltered
+    images include exact copies of reference features (distance == thres is kept: `<=`).  Stored per class: the
+    reference features in the order the function consumed them (glob order), its mean and threshold, the unfiltered
+    features and main()'s clean / unclean decision for each.  The S3 cosine rows stay numpy (the tracker golden pins
+    the reference's own cosine through Net.check_if_face_exists)."""
+    import shutil
+    import tempfile
+    D = 512
     rng = np.random.default_rng(61)
-    ref = rng.normal(0, 1, (32, 1, 512)).astype(np.float32)     # model.predict outputs, shape (R,1,D) :84-85
-    mean = np.mean(ref, axis=0)                                  # :86
-    thres = 0
-    for i in range(32):
-        thres = max(thres, np.linalg.norm(mean - ref[i]))       # :89-92
-    E = (mean + rng.normal(0, 1.0, (40, 512)) * rng.uniform(0.6, 1.4, (40, 1))).astype(np.float32)
-    dist = np.array([np.linalg.norm(o - mean) for o in E])      # :189
+    feats = {}
+    root = tempfile.mkdtemp(prefix="sff_golden_")
+    classes = [("AA-FULL", 40, 40), ("BB-SHORT", 5, 23), ("CC-EDGE", 12, 17)]
+    try:
+        for ci, (cls, n_ref, n_unf) in enumerate(classes):
+            centre = rng.normal(0, 1, D).astype(np.float32)
+            for kind, n in (("ref", n_ref), ("unf", n_unf)):
+                d = os.path.join(root, kind, cls)
+                os.makedirs(d)
+                for k in range(n):
+                    name = f"{cls}_{kind}_{k:03d}.jpg"
+                    with open(os.path.join(d, name), "wb") as f:
+                        f.write(b"not a jpeg: the tensorflow stub never decodes")
+                    spread = 0.35 if kind == "ref" else rng.uniform(0.15, 0.75)
+                    feats[name] = (centre + rng.normal(0, spread, D)).astype(np.float32)
+            if cls == "CC-EDGE":                     # unfiltered images that ARE reference images (dist == thres for one)
+                for k in range(6):
+                    feats[f"{cls}_unf_{k:03d}.jpg"] = feats[f"{cls}_ref_{k:03d}.jpg"].copy()
+        log = []
+        ffr = rh.import_reference_filter(lambda p: feats[os.path.basename(p)], log)
+        out = {"classes": np.array([c[0] for c in classes])}
+        model = ffr.tf.keras.models.load_model("stub")
+        for ci, (cls, n_ref, n_unf) in enumerate(classes):
+            del log[:]
+            mean, thres = ffr.get_ref_mean_vec_and_thres_from_imgs(model, os.path.join(root, "ref", cls), 32)
+            used = [os.path.basename(p) for p in log]
+            assert len(used) == min(32, n_ref) and mean.shape == (1, D)
+            out[f"c{ci}_ref"] = np.stack([feats[u] for u in used])
+            out[f"c{ci}_mean"] = np.asarray(mean[0], np.float32)
+            out[f"c{ci}_thres"] = np.float32(thres)
+        # main(): the reference pairs ref / unfiltered classes by glob order of the two roots; give it sorted-stable names
+        tgt = os.path.join(root, "out")
+        argv = sys.argv
+        sys.argv = ["filter_faces_using_reference.py", "--ud", os.path.join(root, "unf"), "--rd", os.path.join(root, "ref"),
+                    "--td", tgt, "-b", "7", "-r", "32"]
+        try:
+            import glob as _glob
+            order_ref = [os.path.basename(p) for p in _glob.glob(os.path.join(root, "ref", "*"))]
+            order_unf = [os.path.basename(p) for p in _glob.glob(os.path.join(root, "unf", "*"))]
+            assert order_ref == order_unf, "glob order of the two roots differs on this filesystem: main() would raise"
+            ffr.main()
+        finally:
+            sys.argv = argv
+        for ci, (cls, n_ref, n_unf) in enumerate(classes):
+            names = sorted(f"{cls}_unf_{k:03d}.jpg" for k in range(n_unf))
+            clean = set(os.listdir(os.path.join(tgt, "clean", cls)))
+            unclean = set(os.listdir(os.path.join(tgt, "unclean", cls)))
+            assert clean | unclean == set(names) and not (clean & unclean)
+            out[f"c{ci}_E"] = np.stack([feats[n] for n in names])
+            out[f"c{ci}_keep"] = np.array([n in clean for n in names])
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    # legacy keys = class 0 (what the HIP tests read); dist has no reference output (main() only acts on the comparison)
+    mean0, thres0 = out["c0_mean"], out["c0_thres"]
+    dist = np.array([np.linalg.norm(o - mean0) for o in out["c0_E"]])
     a = rng.normal(0, 1, (64, 512)).astype(np.float32)
     b = rng.normal(0, 1, (32, 512)).astype(np.float32)
     cos = np.array([[1 - np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y)) for y in b] for x in a])
-    save("similarity", ref=ref[:, 0], mean=mean[0], thres=np.float32(thres), E=E, dist=dist, keep=dist <= thres,
-         cos_a=a, cos_b=b, cos_dist=cos)
+    save("similarity", ref=out["c0_ref"], mean=mean0, thres=thres0, E=out["c0_E"], dist=dist, keep=out["c0_keep"],
+         cos_a=a, cos_b=b, cos_dist=cos, **out)
 
 
 def gen_yolo():

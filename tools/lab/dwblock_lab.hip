@@ -20,7 +20,7 @@ static void run(int Nmax) {
   const int lds = K::LDS_FLOATS * 4;
   hipFuncSetAttribute((const void*)dwblock_kernel<C, HW, RB, NIMG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   int occ = -1;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dwblock_kernel<C, HW, RB, NIMG>, 256, lds);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dwblock_kernel<C, HW, RB, NIMG>, 512, lds);
   printf("dwblock<%d,%d,%d,%d>: LDS %d B, occupancy query = %d blocks per CU\n", C, HW, RB, NIMG, lds, occ);
   const long elems = (long)Nmax * HW * HW * C;
   const int G = 2 * C;
@@ -35,7 +35,7 @@ static void run(int Nmax) {
   hipMemcpy(x, hx.data(), elems * 4, hipMemcpyHostToDevice);
   hipMemcpy(w, hw.data(), wfl * 4, hipMemcpyHostToDevice);
   unsigned long long* stamps;
-  const size_t ns = 8 * 4 * 8 * 6;
+  const size_t ns = 8 * 8 * 8 * 5;
   hipMalloc(&stamps, ns * 8);
   DwBlockArgs a;
   a.in = x; a.out = y; a.we = w; a.par = w + (long)C * G; a.wp = a.par + 15L * G; a.has_res = 1; a.stamps = nullptr;
@@ -64,14 +64,15 @@ static void run(int Nmax) {
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(ns);
   hipMemcpy(h.data(), stamps, ns * 8, hipMemcpyDeviceToHost);
-  printf("  cycles per round: [P | E | barrier | D | barrier]   (block, wave)\n");
+  printf("  cycles per step: [first (D for waves 4-7) | E | P | last (D for waves 0-3) | barrier]   (block, wave)\n");
   for (int b = 0; b < 2; ++b)
-    for (int wv = 0; wv < 4; ++wv) {
+    for (int wv = 0; wv < 8; ++wv) {
       printf("  b%d w%d:", b, wv);
       for (int c = 0; c < 8 && c < G / 32; ++c) {
-        const unsigned long long* t = &h[((b * 4 + wv) * 8 + c) * 6];
+        const unsigned long long* t = &h[((b * 8 + wv) * 8 + c) * 5];
+        const unsigned long long nxt = c + 1 < 8 && c + 1 < G / 32 ? h[((b * 8 + wv) * 8 + c + 1) * 5] : t[4];
         printf("  [%5lld %5lld %5lld %5lld %5lld]", (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]),
-               (long long)(t[4] - t[3]), (long long)(t[5] - t[4]));
+               (long long)(t[4] - t[3]), (long long)(nxt - t[4]));
       }
       printf("\n");
     }
@@ -81,7 +82,7 @@ static void run(int Nmax) {
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 128, HW = argc > 2 ? atoi(argv[2]) : 14;
   if (C == 128 && HW == 14) run<128, 14, 14, 1>(1024);
-  else if (C == 128 && HW == 7) run<128, 7, 7, 2>(2048);
+  else if (C == 128 && HW == 7) run<128, 7, 7, 3>(3072);
   else run<64, 28, 7, 1>(1024);
   return 0;
 }

@@ -49,6 +49,68 @@ def install_stubs():
             _stub("requests")
 
 
+def install_tensorflow_stub(feature_of_path, log):
+    """A `tensorflow` stand-in with exactly the surface similar_face_filtering/filter_faces_using_reference.py
+    touches (TF is absent offline).  Images are never decoded: tf.io.read_file returns the path itself and
+    the tf.image.* calls pass it through, so read_and_preprocess_img(path) -> path; tf.data.Dataset keeps Python
+    lists; the "model" maps a batch of paths to the feature rows feature_of_path(path) and appends the paths to `log`.
+    Everything else -- glob order, the mean, the threshold, the <= comparison, the clean / unclean copies -- is the
+    reference's own code."""
+    import numpy as np
+
+    class Dataset:
+        def __init__(self, items, batch=None):
+            self.items, self.bs = list(items), batch
+
+        @staticmethod
+        def from_tensor_slices(x):
+            return Dataset(x)
+
+        def map(self, fn):
+            return Dataset([fn(i) for i in self.items])
+
+        def batch(self, k):
+            return Dataset(self.items, int(k))
+
+        def __len__(self):
+            return len(self.items) if self.bs is None else -(-len(self.items) // self.bs)
+
+        def __iter__(self):
+            if self.bs is None:
+                return iter(self.items)
+            return (self.items[i:i + self.bs] for i in range(0, len(self.items), self.bs))
+
+    class Model:
+        inputs, outputs = ["stub input"], ["stub output"]
+
+        def predict(self, batch, verbose=0):
+            log.extend(batch)
+            return np.stack([np.asarray(feature_of_path(p), dtype=np.float32) for p in batch])
+
+    ident = lambda x, *a, **k: x
+    tf = _stub("tensorflow", Tensor=object, float32="float32")
+    tf.random = types.SimpleNamespace(set_seed=lambda s: None)
+    tf.io = types.SimpleNamespace(read_file=ident)
+    tf.image = types.SimpleNamespace(decode_jpeg=ident, convert_image_dtype=ident, resize=ident,
+                                     per_image_standardization=ident)
+    tf.data = types.SimpleNamespace(Dataset=Dataset)
+    tf.keras = types.SimpleNamespace(Model=Model, models=types.SimpleNamespace(load_model=lambda path, compile=False: Model()))
+    return tf
+
+
+def import_reference_filter(feature_of_path, log):
+    """similar_face_filtering/filter_faces_using_reference.py imported unmodified on top of the tensorflow stub."""
+    install_tensorflow_stub(feature_of_path, log)
+    sff = os.path.join(REF, "similar_face_filtering")
+    if sff not in sys.path:
+        sys.path.insert(0, sff)
+    env = dict(os.environ)                       # the module sets XLA / OMP / CUDA_VISIBLE_DEVICES at import: undo
+    import filter_faces_using_reference as ffr
+    os.environ.clear()
+    os.environ.update(env)
+    return ffr
+
+
 def import_reference():
     """Returns a namespace with the reference's hot-path classes/functions."""
     install_stubs()
