@@ -76,7 +76,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
   const bool ext_in = op.kind == FP_OP_YSTEM_U8 || op.kind == FP_OP_STEM_U8;   // input in an external buffer (checked at launch)
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
-                    op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
+                    op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
   if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
@@ -84,8 +84,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
     return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
-  if (in_rp && !fp_blazeblock_wp_eligible(op) && !fp_blazeblock_wps_eligible(op)) return FP_ERR_UNSUPPORTED;
-  if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_STEM_U8 || op.kind == FP_OP_COPY ||
+  if (in_rp && !fp_blazeblock_wp_eligible(op) && !fp_blazeblock_wps_eligible(op) && !fp_blazepair_supported(op))
+    return FP_ERR_UNSUPPORTED;
+  if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_STEM_U8 || op.kind == FP_OP_COPY ||
                   (op.kind == FP_OP_CONV && fp_stem_eligible(op))))
     return FP_ERR_UNSUPPORTED;
   if (out_rp && (op.out_cmul != 1 || op.out_ld != Cout)) return FP_ERR_UNSUPPORTED;
@@ -113,7 +114,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
-      op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_YSTEM || ext_in) {
+      op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_YSTEM || ext_in) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -150,6 +151,13 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.act2 != FP_ACT_NONE && op.act2 != FP_ACT_SILU) return FP_ERR_INVALID_ARG;
   } else if (op.act2 != FP_ACT_NONE) {
     return FP_ERR_INVALID_ARG;
+  }
+  if (op.kind == FP_OP_BLAZEPAIR) {
+    // both blocks' parameters back to back (facepath.h BLAZEPAIR)
+    if (!fp_blazepair_supported(op)) return FP_ERR_UNSUPPORTED;
+    if (!span_ok(op.w_off, 2 * 9 * 24, weight_floats) || !span_ok(op.scale_off, 2 * 24, weight_floats) ||
+        !span_ok(op.slope_off, 2 * 768, weight_floats) || !span_ok(op.bias_off, 2 * 24, weight_floats))
+      return FP_ERR_BOUNDS;
   }
   if (op.kind == FP_OP_DWBLOCK) {
     // w_off: expand packed as CONV (K = Cin, Npad = Cmid); scale_off: [15][Cmid]; slope_off: project packed as CONV
@@ -204,6 +212,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_BLAZEBLOCK:
     case FP_OP_DWPW:
     case FP_OP_DWBLOCK:
+    case FP_OP_BLAZEPAIR:
     case FP_OP_YSTEM:
     case FP_OP_YSTEM_U8:
     case FP_OP_STEM_U8:
@@ -264,6 +273,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;
+    case FP_OP_BLAZEPAIR:
+      snprintf(buf, sizeof(buf), "blazepair_kernel<%d>", op->W);
+      return buf;
     case FP_OP_DWBLOCK:
       snprintf(buf, sizeof(buf), "dwblock_kernel<%d, %d, %d, %d>", op->Cin, op->H, op->H == 28 ? 7 : op->H, op->H == 7 ? 3 : 1);
       return buf;
@@ -298,6 +310,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
     case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
     case FP_OP_DWBLOCK: return fp_launch_dwblock(op, weights, arena, s);
+    case FP_OP_BLAZEPAIR: return fp_launch_blazepair(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);
     case FP_OP_STEM_U8: return fp_launch_stem_u8(op, weights, arena, ext, n_ext, s);

@@ -81,6 +81,9 @@ bool fp_blazeblock_fixed24(const fp_op& op);   // persistent BlazeBlock instanti
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel / dwpw_wp_kernel, false: dwpw_kernel
 bool fp_dwpw_wave_private(const fp_op& op); // true: dwpw_wp_kernel (projection weights resident in LDS)
+bool fp_blazepair_supported(const fp_op& op);   // two stride-1 24 -> 24 BlazeBlocks in one kernel (blazepair.hip)
+int fp_blazepair_band_rows(const fp_op& op);
+int fp_launch_blazepair(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwblock_supported(const fp_op& op); // whole Depth_Wise block shapes dwblock.hip is instantiated for
 int fp_launch_dwblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take the wave-private streaming kernel

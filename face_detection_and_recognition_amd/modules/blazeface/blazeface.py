@@ -31,6 +31,20 @@ class BlazeBlock(_NoCompute):
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
     ROWPAD = True  # class-wide switch: False keeps every activation dense (A/B parity tests)
+    PAIR = True    # class-wide switch: two consecutive stride-1 24 -> 24 blocks as ONE op (FP_OP_BLAZEPAIR, csrc/blazepair.hip)
+
+    def pairs_with(self, other, pb, x):
+        """True if self followed by `other`, fed the row-padded view x, runs as one FP_OP_BLAZEPAIR."""
+        ok = lambda b: (isinstance(b, BlazeBlock) and b.kernel_size == 3 and b.stride == 1 and b.in_channels == 24 and
+                        b.out_channels == 24)
+        return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and BlazeBlock.PAIR and ok(self) and ok(other) and
+                pb.blazepair_supported(x))
+
+    def emit_pair(self, other, pb, x, out_rowpad=False):
+        y = (pb.new_buf_rowpad if out_rowpad else pb.new_buf)(x.H, x.W, 24)
+        pb.blazepair(x, [(npy(b.convs[0].weight), npy(b.convs[0].bias), npy(b.convs[1].weight), npy(b.convs[1].bias))
+                         for b in (self, other)], y.view())
+        return y
 
     def wide_ok(self, H, W):
         """True if this block on an H x W map runs on the small-map wave-private kernel (csrc/blazewp.hip
@@ -232,14 +246,21 @@ class BlazeFace(nn.Module):
         else:
             pb.stem_u8((H, W, frame_hw[0], frame_hw[1], 0), npy(stem.weight), x.view(), pad=(1, 1), bias=npy(stem.bias),
                        act=L.ACT_RELU)
-        for i, blk in enumerate(blocks):
-            if isinstance(blk, BlazeBlock):
+        i = 0
+        while i < len(blocks):
+            blk = blocks[i]
+            if (isinstance(blk, BlazeBlock) and i + 1 < len(blocks) and isinstance(blocks[i + 1], BlazeBlock) and
+                    blk.pairs_with(blocks[i + 1], pb, x.view())):
+                y = blk.emit_pair(blocks[i + 1], pb, x.view(), out_rowpad=rowpad_for(i + 2, x.H, x.W))
+                i += 1
+            elif isinstance(blk, BlazeBlock):
                 oh, ow = (x.H // 2, x.W // 2) if blk.stride == 2 else (x.H, x.W)
                 y = blk.emit(pb, x.view(), out_rowpad=blk.fused(pb, x.view()) and rowpad_for(i + 1, oh, ow))
             else:
                 y = blk.emit(pb, x.view())
             pb.free(x)
             x = y
+            i += 1
         if self.back_model:
             h = self.final.emit(pb, x.view())
         else:

@@ -318,6 +318,34 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (x.H * x.W * cin + opix * cin + opix * cin + opix * cout))
         return out
 
+    @staticmethod
+    def blazepair_supported(x):
+        """Mirror of fp_blazepair_supported (csrc/blazepair.hip): a row-padded 24-channel map, 128 or 64 pixels wide."""
+        return (x.buf.rowpad and x.coff == 0 and x.C == 24 and x.buf.ld == 24 and x.W in (128, 64) and x.H % 8 == 0 and
+                x.H >= 64)
+
+    def blazepair(self, x, blocks, out):
+        """Two consecutive stride-1 24 -> 24 BlazeBlocks (blazeface.py:12-47) as ONE op (FP_OP_BLAZEPAIR): blocks =
+        ((dw_w, dw_b, pw_w, pw_b), (dw_w, dw_b, pw_w, pw_b)); the tensor between them never reaches HBM."""
+        assert self.blazepair_supported(x) and len(blocks) == 2 and out.C == 24 and out.coff == 0 and out.buf.ld == 24
+        op = self._base(L.OP_BLAZEPAIR, x, out, out.H, out.W)
+        op.Cout = 24
+        op.KH = op.KW = 3
+        op.stride = 1
+        op.pad_t = op.pad_l = 1
+        op.act, op.res_mode, op.res_C = L.ACT_RELU, L.RES_ADD_BEFORE_ACT, 24
+        op.res_ld, op.res_ns, op.res_off, op.res_H, op.res_W = op.in_ld, op.in_ns, op.in_off, x.H, x.W
+        for wd, bd, wp, bp in blocks:
+            assert wd.shape == (24, 1, 3, 3) and wp.shape[:2] == (24, 24)
+        op.w_off = self.add_weight(np.concatenate([pack_dw_weight(b[0], 24) for b in blocks]))
+        op.scale_off = self.add_weight(np.concatenate([pad_vec(b[1], 24) for b in blocks]))
+        op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(b[2], 24, 24) for b in blocks]))
+        op.bias_off = self.add_weight(np.concatenate([pad_vec(b[3], 24) for b in blocks]))
+        self.ops.append(op)
+        pix = out.H * out.W
+        self.alg_bytes.append(2 * 4 * self.N * pix * 24 * 4)      # SURVEY 8(d): two blocks, four tensor passes each
+        return out
+
     def dwpw(self, x, dw_w, dw_scale, dw_bias, dw_slope, pw_w, pw_scale, pw_bias, out, stride, res=None,
              out_slope=None, out_act=L.ACT_NONE, shuffle=False):
         """Fused Depth_Wise tail (mobile_facenet.py:72-85): dw3x3 stride s (+BN affine, +PReLU) -> 1x1 (+BN affine)

@@ -70,6 +70,8 @@ enum fp_op_kind {
                            fp_letterbox_tables) happens while the input tile is staged; needs fp_plan_run_ext */
   FP_OP_STEM_U8 = 11,   /* first conv of a network (KxK in {3,5}, stride 2, Cout <= 64, dense NHWC output; BlazeFace's stem,
                            blazeface.py:118-120,195) reading the u8 frames the same way; needs fp_plan_run_ext */
+  FP_OP_BLAZEPAIR = 13, /* TWO consecutive stride-1 24 -> 24 BlazeBlocks (blazeface.py:12-47,122-152) in one kernel: the tensor
+                           between them stays in an LDS ring.  Row-padded input, 128- or 64-pixel-wide map; see "BLAZEPAIR" */
   FP_OP_DWBLOCK = 12    /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
                            dw3x3 stride 1 (+BN, PReLU) -> 1x1 project (+BN) [+ x]; the expanded tensor (Cmid channels)
                            lives in LDS only.  Shapes: see "DWBLOCK" below; anything else fails validation */
@@ -182,8 +184,13 @@ typedef struct fp_op {
  *            scale_off -> [15][Cmid]: rows 0..2 expand BN scale / BN bias / PReLU slope, rows 3..11 the depthwise taps
  *                         (ky*3 + kx), rows 12..14 depthwise BN scale / BN bias / PReLU slope
  *            slope_off -> project weights packed as CONV (K = Cmid, Npad = Cout), then [Cout] BN scale, [Cout] BN bias
+ *   BLAZEPAIR : in = x (row-padded, FP_OPF_IN_ROWPAD, 24 channels, W = 128 or 64, H a multiple of 8 with H / band rows
+ *            >= 2), out = y2 (dense or FP_OPF_OUT_ROWPAD); act = FP_ACT_RELU, res_mode = FP_RES_ADD_BEFORE_ACT (each
+ *            block's shortcut is its own input).  The two blocks' parameters back to back, each as for BLAZEBLOCK:
+ *            w_off -> [2][9][24] taps, scale_off -> [2][24] depthwise bias, slope_off -> [2] packed 1x1 (K = 24,
+ *            Npad = 32: 768 floats each), bias_off -> [2][24] 1x1 bias.
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0 and FP_OP_DWBLOCK.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

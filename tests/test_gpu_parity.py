@@ -210,6 +210,60 @@ def test_blazeblock_row_padded_layouts_vs_oracle(dev, stride, in_rp, out_rp, n, 
         assert float(region.abs().sum()) > 0 and float(left.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("hw,n,out_rp", [
+    ((128, 128), 3, True),     # four strips per row, 8-row bands (few images): every band boundary case
+    ((128, 128), 20, False),   # dense output
+    ((64, 64), 5, True),       # two bands per workgroup, odd band count: the last workgroup's second half is idle
+    ((64, 64), 16, False),
+    ((64, 128), 2, True),      # non-square map
+])
+def test_blazepair_two_blocks_in_one_kernel_vs_oracle(dev, hw, n, out_rp):
+    """FP_OP_BLAZEPAIR (csrc/blazepair.hip): two stride-1 24 -> 24 BlazeBlocks, the tensor between them kept in an LDS
+    ring, against blazeface_ref._blaze_block applied twice (torch fp32 on the CPU; blazeface.py:12-47) and against the
+    two single-block launches on the same input (same arithmetic per block: 2e-6 of scale)."""
+    H, W = hw
+    rng = np.random.default_rng(500 + H + n)
+    blks = [BlazeBlock(24, 24), BlazeBlock(24, 24)]
+    sds = []
+    for k, b in enumerate(blks):
+        sd = synth_state_dict(b.state_dict(), 1500 + k)
+        b.load_state_dict(sd)
+        sds.append(sd)
+    x = rng.normal(0, 1, (n, 24, H, W)).astype(np.float32)
+    outs = {}
+    for pair in (True, False):
+        pb = PlanBuilder(n)
+        inp = pb.new_buf_rowpad(H, W, 24)
+        if pair:
+            assert blks[0].pairs_with(blks[1], pb, inp.view())
+            y = blks[0].emit_pair(blks[1], pb, inp.view(), out_rowpad=out_rp)
+        else:
+            mid = blks[0].emit(pb, inp.view(), out_rowpad=True)
+            y = blks[1].emit(pb, mid.view(), out_rowpad=out_rp)
+        plan = CompiledPlan(pb, dev)
+        names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+        assert names == (["blazepair_kernel<%d>" % W] if pair else ["blazeblock_wp_kernel<24, 4>"] * 2), names
+        plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+        yt = plan.buf_tensor(y, n)
+        yt.fill_(float("nan"))
+        plan.run()
+        torch.cuda.synchronize()
+        outs[pair] = yt.permute(0, 3, 1, 2).cpu().numpy()
+        if out_rp:          # the pads of a row-padded output stay zero (the next block's window reads them)
+            full = plan.arena[y.off - (W + 2) * 24: y.off - (W + 2) * 24 + n * y.ns].clone()
+            yt.zero_()
+            assert float(plan.arena[y.off - (W + 2) * 24: y.off - (W + 2) * 24 + n * y.ns].abs().max()) == 0.0
+            assert float(full.abs().sum()) > 0
+    t = torch.from_numpy(x)
+    for sd in sds:
+        t = blazeface_ref._blaze_block(sd, "", t, 1)
+    ref = t.numpy()
+    assert outs[True].shape == ref.shape and np.isfinite(outs[True]).all()
+    assert rel_err(outs[True], ref) < 1e-5
+    np.testing.assert_allclose(outs[True], ref, rtol=1e-5, atol=2e-5)
+    assert rel_err(outs[True], outs[False]) < 2e-6
+
+
 def test_blazeblock_fused_ragged_tail(dev):
     """M = N*OH*OW not a multiple of the 128-row tile, odd batch: the tail tile must not write out of range."""
     rng = np.random.default_rng(12)

@@ -36,6 +36,8 @@ def profile(plan, name, reps=10):
             fl = 2.0 * op.N * op.OH * op.OW * op.KH * op.KW * op.Cin
         elif op.kind == L.OP_BLAZEBLOCK:
             fl = 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
+        elif op.kind == L.OP_BLAZEPAIR:
+            fl = 2 * 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
         elif op.kind == L.OP_DWPW:
             fl = 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
         elif op.kind == L.OP_DWBLOCK:
