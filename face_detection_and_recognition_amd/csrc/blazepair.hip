@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
   // this wave's band: (image, band) -> first output row y0; the two halves of a 64-wide workgroup take bands 2b, 2b + 1
   const int bi = min((int)blockIdx.x * NSUB + sub, p.nbands - 1);
   const bool live = (int)blockIdx.x * NSUB + sub < p.nbands;
-  const unsigned img = fp_fastdiv((unsigned)bi, p.bands_div);
-  const int y0 = (bi - (int)img * p.bands) * p.R;
+  const unsigned img = __builtin_amdgcn_readfirstlane(fp_fastdiv((unsigned)bi, p.bands_div));
+  const int y0 = __builtin_amdgcn_readfirstlane((bi - (int)img * p.bands) * p.R);   // wave-uniform: the row tests below are scalar branches
   const long in_rb = (long)p.in_rp * 4, out_rb = (long)p.out_rp * 4;
   const char* inb = (const char*)p.in + fp_uniform(((long)img * p.in_ns + (long)(x0 - 1) * C) * 4);    // (row 0, column x0 - 1)
   char* outb = (char*)p.out + fp_uniform(((long)img * p.out_ns + (long)x0 * C) * 4);                   // (row 0, column x0)

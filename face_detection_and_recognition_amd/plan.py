@@ -549,6 +549,8 @@ class PlanBuilder:
                 shift = round_up(self.peak, 64)
                 for op in self.ops:
                     if op.flags & L.OPF_IN_ROWPAD:
+                        if op.kind == L.OP_BLAZEPAIR:
+                            op.res_off += shift      # its shortcut view IS its input view
                         op.in_off += shift
                     if op.flags & L.OPF_OUT_ROWPAD:
                         op.out_off += shift
@@ -692,6 +694,32 @@ class CompiledPlan:
     def kernel_name(self, i):
         """The HIP kernel family op i launches (matches the rocprofv3 kernel-trace names)."""
         return self.lib.fp_op_kernel_name(C.byref(self.ops[i])).decode()
+
+    def compulsory_bytes(self, i, n=None):
+        """Bytes op i MUST move for a batch of n images (default: the batch the plan last ran on): every tensor it reads
+        once + every tensor it writes once, physical channel counts, weights not counted (they are re-read from L2).
+        A fused op is charged for its inputs and outputs only -- the tensors between the reference ops it replaces never
+        exist -- so this is the denominator of a physical roofline fraction (bench.py `roofline.frac`); the SURVEY 8(d)
+        op-granular figure is algorithmic_bytes()."""
+        op = self.ops[i]
+        n = self.n_run if n is None else n
+        k = op.kind
+        if k in (L.OP_STEM_U8, L.OP_YSTEM_U8):
+            b_in = op.res_H * op.res_W * 3                       # u8 frame
+        else:
+            b_in = op.H * op.W * op.Cin * 4
+        cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_YSTEM, L.OP_YSTEM_U8,
+                                L.OP_STEM_U8) else op.Cin
+        oh, ow = (op.H, op.W) if k in (L.OP_COPY, L.OP_L2NORM) else (op.OH, op.OW)
+        b_out = oh * ow * cout * 4 * (2 if op.res_mode == L.RES_SHUFFLE2 else 1)
+        b_res = 0
+        if k in (L.OP_YSTEM, L.OP_YSTEM_U8):
+            b_res = (op.OH // 2) * (op.OW // 2) * op.res_C * 4   # the pooled stem_1 map it also writes
+        elif (k in (L.OP_CONV, L.OP_DWPW) and op.res_off != op.in_off and
+              op.res_mode in (L.RES_ADD_BEFORE_ACT, L.RES_ADD_AFTER_ACT, L.RES_SHUFFLE2)):
+            b_res = oh * ow * op.res_C * 4                       # a residual that is not the op's own input (the block
+                                                                 # ops' shortcut is their input: read once)
+        return n * (b_in + b_out + b_res)
 
     def algorithmic_bytes(self, i):
         """Op-granular fp32 activation bytes of op i: a conv / linear reads its input once and

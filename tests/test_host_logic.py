@@ -10,7 +10,7 @@ import torch
 
 from conftest import ROOT, golden
 from face_detection_and_recognition_amd import _lib as L
-from face_detection_and_recognition_amd.modules.blazeface.blazeface import BlazeFace, generate_anchors
+from face_detection_and_recognition_amd.modules.blazeface.blazeface import BlazeBlock, BlazeFace, generate_anchors
 from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import MobileFaceNet
 from face_detection_and_recognition_amd.modules.utils import image as uimage
 from face_detection_and_recognition_amd.modules.utils.inference import get_dets_bboxes_confs_lmarks_areas
@@ -63,14 +63,27 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
     pb = BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0]
     ops, weights, arena = pb.finish()
     flags = [op.flags for op in ops]
-    assert flags[0] == L.OPF_OUT_ROWPAD and flags[1] == L.OPF_IN_ROWPAD | L.OPF_OUT_ROWPAD
-    assert flags[7] == L.OPF_IN_ROWPAD and flags[8] == L.OPF_OUT_ROWPAD
-    assert flags[16] == L.OPF_OUT_ROWPAD and flags[23] == L.OPF_IN_ROWPAD     # 24 -> 48 stride 2, last 48 -> 48 block
-    assert flags[24] == 0 and flags[25] == 0 and flags[26] == L.OPF_OUT_ROWPAD  # unfused stride-2 block, then the copy
     names = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops]
-    assert sum(n.startswith("blazeblock_wp_kernel") for n in names) == 14
-    assert sum(n.startswith("blazeblock_wps_kernel<48>") for n in names) == 7
-    assert sum(n.startswith("blazeblock_wps_kernel<96>") for n in names) == 7 and names[26] == "copy4_kernel"
+    both = L.OPF_IN_ROWPAD | L.OPF_OUT_ROWPAD
+    # stem -> 3 pairs + 1 single 24 -> 24 block at 128 x 128 -> stride 2 -> 3 pairs + 1 single at 64 x 64 -> stride 2 -> ...
+    assert names[0].startswith("stem_conv_kernel<5, 1, true>") and flags[0] == L.OPF_OUT_ROWPAD
+    assert names[1:4] == ["blazepair_kernel<128>"] * 3 and flags[1:4] == [both] * 3
+    assert names[4].startswith("blazeblock_wp_kernel") and flags[4] == L.OPF_IN_ROWPAD     # feeds the dense stride-2 block
+    assert flags[5] == L.OPF_OUT_ROWPAD                                                     # 24 -> 24 stride 2
+    assert names[6:9] == ["blazepair_kernel<64>"] * 3 and flags[6:9] == [both] * 3
+    assert names[9].startswith("blazeblock_wp_kernel") and flags[9] == L.OPF_IN_ROWPAD
+    i48 = [i for i, n in enumerate(names) if n.startswith("blazeblock_wps_kernel<48>")]
+    i96 = [i for i, n in enumerate(names) if n.startswith("blazeblock_wps_kernel<96>")]
+    assert len(i48) == 7 and len(i96) == 7 and i48 == list(range(11, 18))
+    assert flags[10] == L.OPF_OUT_ROWPAD and flags[17] == L.OPF_IN_ROWPAD      # 24 -> 48 stride 2, last 48 -> 48 block
+    icopy = names.index("copy4_kernel")
+    assert flags[18] == 0 and flags[19] == 0 and icopy == 20 and flags[20] == L.OPF_OUT_ROWPAD   # unfused stride-2 block, then the copy
+    BlazeBlock.PAIR = False
+    try:
+        names1 = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0].finish()[0]]
+    finally:
+        BlazeBlock.PAIR = True
+    assert sum(n.startswith("blazeblock_wp_kernel") for n in names1) == 14 and not any("blazepair" in n for n in names1)
     arr = (L.FpOp * len(ops))(*ops)
     assert lib.fp_plan_validate(arr, len(ops), weights.size, arena) == 0
     # row-padded buffers sit behind the recycled arena and never share floats with a dense view
@@ -79,7 +92,7 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
         if not op.flags & L.OPF_IN_ROWPAD and op.kind not in (L.OP_STEM_U8,):
             assert op.in_off + (op.N - 1) * op.in_ns + (op.H * op.W - 1) * op.in_ld + op.Cin <= lo
     bad = (L.FpOp * len(ops))(*ops)
-    bad[16].flags |= L.OPF_IN_ROWPAD               # a 24 -> 48 stride-2 block cannot read the padded layout
+    bad[10].flags |= L.OPF_IN_ROWPAD               # a 24 -> 48 stride-2 block cannot read the padded layout
     assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
     bad = (L.FpOp * len(ops))(*ops)
     bad[1].in_off = 8                              # the pad row above image 0 would start before the arena
