@@ -90,6 +90,10 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
                   (op.kind == FP_OP_CONV && fp_stem_eligible(op))))
     return FP_ERR_UNSUPPORTED;
   if (out_rp && (op.out_cmul != 1 || op.out_ld != Cout)) return FP_ERR_UNSUPPORTED;
+  // a row-padded COPY exists only in its 16-byte form (copy4_kernel); the scalar copy would fail at launch
+  if (out_rp && op.kind == FP_OP_COPY &&
+      (op.Cin % 4 || op.in_ld % 4 || op.out_ld % 4 || op.in_off % 4 || op.out_off % 4 || op.in_ns % 4 || op.out_ns % 4))
+    return FP_ERR_UNSUPPORTED;
   // input extent
   if (in_rp) {
     const int64_t lead = (int64_t)(op.W + 2) * op.in_ld;

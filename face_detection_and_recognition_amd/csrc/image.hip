@@ -96,7 +96,7 @@ namespace {
 struct LbTableArgs {
   fp_lb_tap* xtab;
   fp_lb_tap* ytab;
-  int fw, cw, ch, sx, sy, sw, sh, dx, dy, dw, dh, pad_value, swap_rb;
+  int fw, cw, ch, sx, sy, sw, sh, dx, dy, dw, dh, pad_value, swap_rb, fh;
 };
 
 __global__ __launch_bounds__(256) void letterbox_tables_kernel(LbTableArgs p) {
@@ -125,6 +125,11 @@ __global__ __launch_bounds__(256) void letterbox_tables_kernel(LbTableArgs p) {
   } else if (i == p.cw + p.ch) {
     const fp_lb_tap t = {p.pad_value, p.swap_rb};     // trailer: pad colour (u8 value), swap R/B
     p.xtab[i] = t;
+  } else if (i == p.cw + p.ch + 1) {
+    // geometry the taps were built for: the *_U8 stems refuse tables of another frame / canvas size (their 8-byte
+    // window loads would leave the frames buffer)
+    const fp_lb_tap t = {p.fh | (p.fw << 16), p.ch | (p.cw << 16)};
+    p.xtab[i] = t;
   }
 }
 
@@ -133,13 +138,15 @@ __global__ __launch_bounds__(256) void letterbox_tables_kernel(LbTableArgs p) {
 extern "C" int fp_letterbox_tables(int frame_h, int frame_w, int canvas_h, int canvas_w, int sx, int sy, int sw, int sh,
                                    int dx, int dy, int dw, int dh, int pad_value, int swap_rb, int32_t* tables,
                                    void* stream) {
-  if (!tables || frame_h <= 0 || frame_h > 65535 || frame_w < 3 || canvas_h <= 0 || canvas_w <= 0) return FP_ERR_INVALID_ARG;
+  if (!tables || frame_h <= 0 || frame_h > 65535 || frame_w < 3 || frame_w > 32767 || canvas_h <= 0 || canvas_w <= 0 ||
+      canvas_h > 65535 || canvas_w > 32767)
+    return FP_ERR_INVALID_ARG;
   if (sx < 0 || sy < 0 || sw <= 0 || sh <= 0 || sx + sw > frame_w || sy + sh > frame_h) return FP_ERR_INVALID_ARG;
   if (dw < 0 || dh < 0 || dx < 0 || dy < 0 || dx + dw > canvas_w || dy + dh > canvas_h) return FP_ERR_INVALID_ARG;
   if (pad_value < 0 || pad_value > 255) return FP_ERR_INVALID_ARG;
   LbTableArgs a{(fp_lb_tap*)tables, (fp_lb_tap*)tables + canvas_w, frame_w, canvas_w, canvas_h, sx, sy, sw, sh, dx, dy, dw, dh,
-                pad_value, swap_rb != 0};
-  hipLaunchKernelGGL(letterbox_tables_kernel, dim3((unsigned)fp_ceil_div(canvas_w + canvas_h + 1, 256)), dim3(256), 0,
+                pad_value, swap_rb != 0, frame_h};
+  hipLaunchKernelGGL(letterbox_tables_kernel, dim3((unsigned)fp_ceil_div(canvas_w + canvas_h + 2, 256)), dim3(256), 0,
                      (hipStream_t)stream, a);
   FP_CHECK_LAUNCH();
   return FP_OK;

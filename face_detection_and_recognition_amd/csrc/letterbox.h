@@ -11,7 +11,9 @@
 //             sh0 / sh1 = byte position of tap 0 / tap 1 inside it, a0 / a1 = the 11-bit fixed-point weights
 //   ytab[y] = { row0 | row1 << 16, b0 | b1 << 12 | valid << 30 }      frame rows of the vertical taps, weights
 // valid = 0 marks a canvas column (row) outside the destination rectangle: the pixel is the pad colour.
-// The entry after the last row is a trailer { pad colour (u8 value), swap R/B }.
+// The entry after the last row is a trailer { pad colour (u8 value), swap R/B }, the one after it the geometry the
+// tables were built for { frame_h | frame_w << 16, canvas_h | canvas_w << 16 }: a stem that is handed tables of another
+// geometry writes nothing (fp_lb_geometry_ok) instead of loading outside the frames.
 #pragma once
 #include "common.h"
 
@@ -36,6 +38,12 @@ __device__ __forceinline__ void fp_lb_coef(int d, double scale, int ssize, int& 
   s1 = min(s + 1, ssize - 1);
   a0 = (int)rintf((1.f - f) * 2048.f);
   a1 = (int)rintf(f * 2048.f);
+}
+
+// true if the tables (trailer entry W + H + 1) were built for this frame / canvas size
+__device__ __forceinline__ bool fp_lb_geometry_ok(const fp_lb_tap* tabs, int W, int H, int frame_h, int frame_w) {
+  const fp_lb_tap g = tabs[W + H + 1];
+  return g.a == (frame_h | (frame_w << 16)) && g.b == (H | (W << 16));
 }
 
 // Vertical pass + clamp for one channel from the two horizontal sums.

@@ -37,6 +37,7 @@ struct StemArgs {
   const fp_lb_tap* tabs;     // [W] column taps, [H] row taps, trailer {pad colour, swap R/B}
   const float* lut;
   long frame_bytes, row_bytes;
+  int frame_h, frame_w;
 };
 
 constexpr int TMS = 128;
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemArgs p) {
 
   int pad_value = 0, swap_rb = 0;
   if (U8) {
+    if (!fp_lb_geometry_ok(p.tabs, p.W, p.H, p.frame_h, p.frame_w)) return;   // tables of another geometry (uniform)
     LutS[tid] = p.lut[tid];
     for (int i = tid; i < p.W + p.H; i += 256) TabS[i] = p.tabs[i];
     const fp_lb_tap tr = p.tabs[p.W + p.H];
@@ -279,6 +281,7 @@ static void stem_fill(const fp_op& op, const float* weights, float* arena, StemA
   a.ow_div = fp_make_divisor((unsigned)(op.OW >= 2 ? op.OW : 2));
   a.frames = nullptr; a.tabs = nullptr; a.lut = nullptr;
   a.frame_bytes = a.row_bytes = 0;
+  a.frame_h = a.frame_w = 0;
 }
 
 template <bool U8>
@@ -327,7 +330,7 @@ int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const
   if (e < 0 || e + 2 >= n_ext || !ext) return FP_ERR_INVALID_ARG;
   const int fh = op.res_H, fw = op.res_W;
   if (op.Cin != 3 || fh <= 0 || fw < 3 || !fp_stem_u8_shape_ok(op)) return FP_ERR_UNSUPPORTED;
-  if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 1) * 8 ||
+  if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 2) * 8 ||
       ext[e + 2].bytes < 256 * sizeof(float) || !ext[e].ptr || !ext[e + 1].ptr || !ext[e + 2].ptr)
     return FP_ERR_BOUNDS;
   StemArgs a;
@@ -337,5 +340,7 @@ int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const
   a.lut = (const float*)ext[e + 2].ptr;
   a.row_bytes = (long)fw * 3;
   a.frame_bytes = (long)fh * fw * 3;
+  a.frame_h = fh;
+  a.frame_w = fw;
   return stem_launch<true>(op, a, s);
 }

@@ -48,6 +48,7 @@ struct YStemArgs {
   const fp_lb_tap* ytab;
   const float* lut;
   long frame_bytes, row_bytes;
+  int frame_h, frame_w;
 };
 
 template <int NB2, bool U8>
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void ystem_kernel(YStemArgs p) {
   for (int i = tid; i < 8 * C2S; i += 256) *(f32x4*)&W2s[i * 4] = *(const f32x4*)(p.w2 + (long)i * 4);
   int pad_value = 0, swap_rb = 0;
   if (U8) {
+    if (!fp_lb_geometry_ok(p.xtab, p.W, p.H, p.frame_h, p.frame_w)) return;   // tables of another geometry (uniform)
     LutS[tid] = p.lut[tid];
     for (int i = tid; i < p.W + p.H; i += 256) TabS[i] = p.xtab[i];
     const fp_lb_tap tr = p.xtab[p.W + p.H];    // trailer entry of the tables: { pad colour, swap R/B }
@@ -285,6 +287,7 @@ static int ystem_fill(const fp_op& op, const float* weights, float* arena, YStem
   a.xtab = a.ytab = nullptr;
   a.lut = nullptr;
   a.frame_bytes = a.row_bytes = 0;
+  a.frame_h = a.frame_w = 0;
   return FP_OK;
 }
 
@@ -327,7 +330,7 @@ int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, cons
   if (e < 0 || e + 2 >= n_ext || !ext) return FP_ERR_INVALID_ARG;
   const int fh = op.res_H, fw = op.res_W;
   if (op.Cin != 3 || fh <= 0 || fw < 3) return FP_ERR_INVALID_ARG;
-  if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 1) * 8 || op.H + op.W > 2048 ||
+  if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 2) * 8 || op.H + op.W > 2048 ||
       ext[e + 2].bytes < 256 * sizeof(float) || !ext[e].ptr || !ext[e + 1].ptr || !ext[e + 2].ptr)
     return FP_ERR_BOUNDS;
   YStemArgs a;
@@ -339,6 +342,8 @@ int fp_launch_ystem_u8(const fp_op& op, const float* weights, float* arena, cons
   a.lut = (const float*)ext[e + 2].ptr;
   a.row_bytes = (long)fw * 3;
   a.frame_bytes = (long)fh * fw * 3;
+  a.frame_h = fh;
+  a.frame_w = fw;
   a.c4 = 0;
   return ystem_launch<true>(op, a, s);
 }

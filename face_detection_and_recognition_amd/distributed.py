@@ -62,8 +62,11 @@ def cross_rank_match(block, n_valid, tau, filter_fn, inv_norm_fn, group=None):
     block (cap, D): this rank's embeddings, first n_valid rows meaningful (n_valid: 1-element device tensor).
     filter_fn(G, R, tau, rinv) -> (best, arg, keep) is the cosine filter (HIP: similarity.cosine_filter);
     inv_norm_fn(R) -> (rows,) inverse row norms.  Own rows and padding rows take part with inverse norm 0
-    (score 0), so nothing is compacted and nothing is read on the host.  Returns (best, arg, keep) for the cap local
-    rows (entries past n_valid are padding) and the gathered counts; arg indexes the gathered matrix (rank * cap + i)."""
+    (score exactly 0), so nothing is compacted and nothing is read on the host.  Returns (best, arg, keep) for the cap
+    local rows (entries past n_valid are padding) and the gathered counts; arg indexes the gathered matrix
+    (rank * cap + i).  A row whose row maximum landed on a masked column -- every cosine against the other ranks' faces
+    is negative, or no other rank found a face -- gets arg = -1, keep = False and best = -1 (a lower bound: the true
+    maximum is negative and the kernel does not return it)."""
     rank = dist.get_rank(group)
     cap = block.shape[0]
     rows, valid, counts = all_gather_blocks(block, n_valid, group)
@@ -71,6 +74,10 @@ def cross_rank_match(block, n_valid, tau, filter_fn, inv_norm_fn, group=None):
     others[rank * cap:(rank + 1) * cap] = False
     rinv = inv_norm_fn(rows) * others.to(rows.dtype)
     best, arg, keep = filter_fn(block, rows, tau, rinv)
+    hit = others[arg.long().clamp_(0, others.shape[0] - 1)]          # did the maximum land on a real peer row?
+    arg = torch.where(hit, arg, torch.full_like(arg, -1))
+    best = torch.where(hit, best, torch.full_like(best, -1.0))
+    keep = keep & hit
     return best, arg, keep, counts
 
 

@@ -356,6 +356,66 @@ class BlazeFace(nn.Module):
             out.append(faces.cpu().numpy() if use_numpy_for_post_proc else faces)
         return out
 
+    # ---- the reference's private post-processing names (blazeface.py:321, :373, :404), same arguments and return
+    # shapes, on the device kernels.  A caller that used them on the reference's BlazeFace drops in.
+    def _as_dev(self, t):
+        return torch.as_tensor(np.asarray(t) if isinstance(t, np.ndarray) else t).to(self._device(), torch.float32).contiguous()
+
+    def _decode_boxes(self, raw_boxes, anchors, use_numpy=False):
+        """blazeface.py:373-402: anchor decode of the whole batch, (b, 896, 16) -> (b, 896, 16) [ymin, xmin, ymax, xmax,
+        6 keypoints].  fp_blaze_decode with a threshold nothing fails, so every anchor comes out, in anchor order."""
+        rb, an = self._as_dev(raw_boxes), self._as_dev(anchors)
+        b, A = rb.shape[0], rb.shape[1]
+        dev = self._device()
+        cand = torch.empty((b, A, 17), dtype=torch.float32, device=dev)
+        cnt = torch.empty((b,), dtype=torch.int32, device=dev)
+        ones = torch.ones((b, A), dtype=torch.float32, device=dev)
+        L.check(L.load().fp_blaze_decode(L.ptr(rb), L.ptr(ones), L.ptr(an), b, A, self.x_scale, self.y_scale, self.w_scale,
+                                         self.h_scale, self.score_clipping_thresh, -1.0, L.ptr(cand), L.ptr(cnt),
+                                         L.current_stream(dev)), "fp_blaze_decode")
+        boxes = cand[..., :16].contiguous()
+        return boxes.cpu().numpy() if use_numpy else boxes
+
+    def _tensors_to_detections(self, raw_box_tensor, raw_score_tensor, anchors, use_numpy=False):
+        """blazeface.py:321-371: raw (b, 896, 16) + (b, 896, 1) -> a list of (num_detections, 17) per image (decode,
+        clip, sigmoid, score >= min_score_thresh), in anchor order."""
+        assert raw_box_tensor.ndim == 3
+        assert raw_box_tensor.shape[1] == self.num_anchors
+        assert raw_box_tensor.shape[2] == self.num_coords
+        assert raw_score_tensor.ndim == 3
+        assert raw_score_tensor.shape[1] == self.num_anchors
+        assert raw_score_tensor.shape[2] == self.num_classes
+        assert raw_box_tensor.shape[0] == raw_score_tensor.shape[0]
+        rb, rs, an = self._as_dev(raw_box_tensor), self._as_dev(raw_score_tensor), self._as_dev(anchors)
+        b, A = rb.shape[0], self.num_anchors
+        dev = self._device()
+        cand = torch.empty((b, A, 17), dtype=torch.float32, device=dev)
+        cnt = torch.empty((b,), dtype=torch.int32, device=dev)
+        L.check(L.load().fp_blaze_decode(L.ptr(rb), L.ptr(rs), L.ptr(an), b, A, self.x_scale, self.y_scale, self.w_scale,
+                                         self.h_scale, self.score_clipping_thresh, self.min_score_thresh, L.ptr(cand),
+                                         L.ptr(cnt), L.current_stream(dev)), "fp_blaze_decode")
+        out = []
+        for i, k in enumerate(cnt.cpu().tolist()):
+            d = cand[i, :k].clone()
+            out.append(d.cpu().numpy() if use_numpy else d)
+        return out
+
+    def _weighted_non_max_suppression(self, detections, use_numpy=False):
+        """blazeface.py:404-458: one image's (count, 17) detections -> a list of blended (17,) detections."""
+        if len(detections) == 0:
+            return []
+        d = self._as_dev(detections)
+        n = d.shape[0]
+        dev = self._device()
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        out = torch.empty((1, n, 17), dtype=torch.float32, device=dev)
+        oc = torch.empty((1,), dtype=torch.int32, device=dev)
+        L.check(L.load().fp_blaze_weighted_nms(L.ptr(d), L.ptr(cnt), 1, n, self.min_suppression_threshold, L.ptr(out),
+                                               L.ptr(oc), None, L.current_stream(dev)), "fp_blaze_weighted_nms")
+        k = int(oc.item())
+        rows = out[0, :k]
+        return [r.cpu().numpy() for r in rows] if use_numpy else [r.clone() for r in rows]
+
     def postprocess(self, r, c):
         """decode + threshold + weighted NMS on device.  Returns (dets [b, 896, 17], counts [b])."""
         assert self.anchors is not None, "call load_anchors()/set_anchors() first"

@@ -59,7 +59,7 @@ def bind_letterbox(plan, frames_u8, lut, pad_value=125, swap_rb=False):
     key = (int(pad_value), bool(swap_rb))
     if plan.tables is None or plan.tables[0] != key:
         sw, sh, left, top = letterbox_geometry(fw, fh, cw, ch)
-        t = torch.empty(((cw + ch + 1) * 2,), dtype=torch.int32, device=frames_u8.device)
+        t = torch.empty(((cw + ch + 2) * 2,), dtype=torch.int32, device=frames_u8.device)
         L.check(L.load().fp_letterbox_tables(fh, fw, ch, cw, 0, 0, fw, fh, left, top, sw, sh, int(pad_value),
                                              int(bool(swap_rb)), L.ptr(t), L.current_stream(frames_u8.device)),
                 "fp_letterbox_tables")

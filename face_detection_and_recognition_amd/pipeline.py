@@ -82,10 +82,18 @@ class FacePipeline:
         cap = max(getattr(self, "_emb_cap", 0), (n_pad + 255) // 256 * 256)
         self._emb_cap = cap
         plan = self.emb.plan_for(cap, n_run=n_pad)
-        self.emb_plan, self.emb_n_pad = plan, n_pad
+        self.emb_key, self.emb_n_pad = (cap, n_pad), n_pad     # the plan itself stays owned by the embedder's LRU cache
         crops_to_input(frames, items, n_faces, plan.input, self.lut)
+        if n_pad > n_faces:
+            plan.input[n_faces:n_pad].zero_()    # padding crops: defined inputs (every op is per-image, their rows are dropped)
         plan.run(n=n_pad)
         return plan.out[:n_faces]
+
+    @property
+    def emb_plan(self):
+        """The embedder plan of the last step (looked up in the embedder's plan cache; not held by the pipeline)."""
+        cap, n_pad = self.emb_key
+        return self.emb.plan_for(cap, n_run=n_pad)
 
     def filter(self, emb):
         if self.reference is None or emb.shape[0] == 0:

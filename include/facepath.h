@@ -129,10 +129,14 @@ typedef struct fp_op {
  * ns >= ((H + 2)*(W + 1) + 1)*ld and off - (W + 2)*ld >= 0 the first float of image 0.  Producers write only
  * y in [0, H), x in [0, W); whoever owns the arena zeroes the pads once (plan.py allocates such buffers from a region
  * it never recycles).  The depthwise taps of the BlazeBlocks (blazeface.py:12-47) read it without clamps or masks.
- *   FP_OPF_IN_ROWPAD  : the input view is row-padded.  FP_OP_BLAZEBLOCK, stride 1, 24 -> 24, OW % 32 == 0, OW >= 64, OH % 4 == 0, OH >= 8
- *                       (blazeblock_wp_kernel); anything else fails with FP_ERR_UNSUPPORTED.
- *   FP_OPF_OUT_ROWPAD : the output view is row-padded.  FP_OP_BLAZEBLOCK on its persistent / wave-private kernels,
- *                       FP_OP_CONV on the stem kernel and FP_OP_STEM_U8.
+ *   FP_OPF_IN_ROWPAD  : the input view is row-padded.  Accepted (exactly fp_plan_validate's list):
+ *                       FP_OP_BLAZEBLOCK stride 1, 24 -> 24, OW % 32 == 0, OW >= 64, OH % 4 == 0, OH >= 8 (blazeblock_wp_kernel);
+ *                       FP_OP_BLAZEBLOCK stride 1, 48 -> 48 or 96 -> 96, W = 16 or 32, H*W % 32 == 0, H*W >= 64
+ *                       (blazeblock_wps_kernel); FP_OP_BLAZEPAIR (always).  Anything else: FP_ERR_UNSUPPORTED.
+ *   FP_OPF_OUT_ROWPAD : the output view is row-padded (out_cmul = 1, out_ld = Cout).  Accepted: FP_OP_BLAZEBLOCK (every
+ *                       kernel form), FP_OP_BLAZEPAIR, FP_OP_STEM_U8, FP_OP_CONV on the stem kernel (KxK stride 2 on a
+ *                       4-float pixel), FP_OP_COPY with 16-byte-aligned views (Cin, strides and offsets multiples of 4:
+ *                       copy4_kernel; the scalar copy cannot write the layout and fails validation).
  */
 #define FP_OPF_IN_ROWPAD 1
 #define FP_OPF_OUT_ROWPAD 2
@@ -168,7 +172,7 @@ typedef struct fp_op {
  *            ceil(Cout/16), zero padded), then [NB2*16] scale, [NB2*16] bias.  Both convs end in SiLU.
  *   YSTEM_U8 : as YSTEM, but the input is EXTERNAL: in_off = index e into the ext[] array of fp_plan_run_ext with
  *            ext[e] = frames [N][fh][fw][3] u8, ext[e+1] = the tap tables fp_letterbox_tables wrote for an H x W canvas
- *            ((W + H + 1) x 8 bytes, W + H <= 2048), ext[e+2] = 256-float normalisation LUT.  H, W = the canvas (model input) size,
+ *            ((W + H + 2) x 8 bytes, W + H <= 2048), ext[e+2] = 256-float normalisation LUT.  H, W = the canvas (model input) size,
  *            Cin = 3, res_H = fh, res_W = fw (the pooled map is OH/2 x OW/2 as for YSTEM).
  *   STEM_U8 : a CONV (weights packed for Cin = 4: k = tap*4 + c, zero fourth channel; scale / bias / slope / act as
  *            CONV, no residual) whose H x W input is the letterbox canvas of external u8 frames: in_off = e with
@@ -276,7 +280,11 @@ int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int fr
  * FP_OP_STEM_U8): source rectangle (sx, sy, sw, sh) of a frame_h x frame_w frame -> destination rectangle
  * (dx, dy, dw, dh) of a canvas_h x canvas_w canvas, everything else pad_value.  Same arithmetic as
  * fp_resize_normalize (pad_resize_image, fde/modules/utils/image.py:31-59), evaluated once per column and row:
- * tables = (canvas_w + canvas_h + 1) entries of 2 int32 (layout: csrc/letterbox.h); frame_h <= 65535.
+ * tables = (canvas_w + canvas_h + 2) entries of 2 int32 (layout: csrc/letterbox.h); frame_h, canvas_h <= 65535,
+ * frame_w, canvas_w <= 32767.  The last entry records (frame_h, frame_w, canvas_h, canvas_w): a *_U8 op that is handed
+ * tables built for another geometry writes NOTHING (a device-side check per workgroup; the host cannot read the device
+ * buffer without a sync).  Trust boundary: the library checks the BYTE SIZES of the three external buffers and that
+ * geometry record; that the frames buffer really holds N frames of res_H x res_W x 3 bytes is the caller's contract.
  */
 int fp_letterbox_tables(int frame_h, int frame_w, int canvas_h, int canvas_w, int sx, int sy, int sw, int sh,
                         int dx, int dy, int dw, int dh, int pad_value, int swap_rb, int32_t* tables /*device*/,

@@ -76,6 +76,18 @@ def _worker(rank, world, port, q):
     ok = ok and counts.tolist() == [17, 9]
     ok = ok and np.allclose(best3.numpy()[:n_loc], sref.max(1), atol=1e-5)
     ok = ok and np.array_equal(arg3.numpy()[:n_loc], (1 - rank) * cap + sref.argmax(1))
+    # every cross-rank cosine negative (rank 0's faces cluster around +c, rank 1's around -c): the row maximum lands on
+    # a masked column (score 0) -> arg -1, keep False, best -1; and a step in which the peer found no face at all
+    centre = rng.normal(0, 1, (1, D_)).astype(np.float32)
+    base = centre + 0.1 * rng.normal(0, 1, (6, D_)).astype(np.float32)
+    blk = np.zeros((cap, D_), np.float32)
+    blk[:6] = base if rank == 0 else -base
+    b4, a4, k4, _ = D.cross_rank_match(torch.from_numpy(blk), torch.tensor([6]), 0.1, filter_rinv, inv_norm)
+    ok = ok and (a4.numpy()[:6] == -1).all() and not k4.numpy()[:6].any() and (b4.numpy()[:6] == -1.0).all()
+    n5 = [5, 0][rank]
+    b5, a5, k5, c5 = D.cross_rank_match(torch.from_numpy(block), torch.tensor([n5]), -0.5, filter_rinv, inv_norm)
+    if rank == 0:      # no peer rows: nothing can match, whatever tau is
+        ok = ok and c5.tolist() == [5, 0] and (a5.numpy()[:5] == -1).all() and not k5.numpy()[:5].any()
     rows_g, valid_g, _ = D.all_gather_blocks(torch.from_numpy(block), torch.tensor([n_loc]))
     ok = ok and valid_g.tolist() == [i < 17 for i in range(cap)] + [i < 9 for i in range(cap)]
     mean = D.sharded_l2_mean(torch.from_numpy(R[r0:r1]))
