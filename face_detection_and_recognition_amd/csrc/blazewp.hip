@@ -189,32 +189,31 @@ __global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
 #pragma unroll
       for (int kq = 0; kq < KG; ++kq) {
         const f32x4 a = *(const f32x4*)(arow + kq * 8);
-        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bfrag[kq][0], m0, 0, 0, 0);
+        // operands swapped: D^T = W^T x A^T, so lane (lr, h) holds PIXEL lr and channels (k & 3) + 8*(k >> 2) + 4h --
+        // 16-byte pieces of a row-major pixel: the epilogue is 3 x (b128 read, adds, b128 write) instead of 16 + 16
+        // scalar LDS accesses (csrc/blazepair.hip has the same form)
+        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bfrag[kq][0], a[0], m0, 0, 0, 0);
         FP_MFMA_ORDER();
-        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bfrag[kq][1], m1, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bfrag[kq][1], a[1], m1, 0, 0, 0);
         FP_MFMA_ORDER();
-        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bfrag[kq][2], m0, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bfrag[kq][2], a[2], m0, 0, 0, 0);
         FP_MFMA_ORDER();
-        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bfrag[kq][3], m1, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bfrag[kq][3], a[3], m1, 0, 0, 0);
         FP_MFMA_ORDER();
       }
-      // ---- shortcut + ReLU -> output tile (two halves: 8 shortcut values in flight, not 16 -- register budget) ----
+      // ---- shortcut + ReLU -> output tile: pixel lr, channels 8j + 4h .. + 3 ----
       {
-        const float* srow = &St[(4 * h) * LDT + (lr < C ? lr : 0)];
-        float* orow = &Ot[(4 * h) * C + lr];
+        const float* spx = &St[lr * LDT + 4 * h];
+        float* opx = &Ot[lr * C + 4 * h];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float sv[8];
+        for (int j = 0; j < C / 8; ++j) {
+          const f32x4 sv = *(const f32x4*)(spx + 8 * j);
+          f32x4 v;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) sv[i] = srow[((i & 3) + 8 * (2 * half + (i >> 2))) * LDT];
-          if (lr < C) {
+          for (int e = 0; e < 4; ++e) v[e] = (m0[4 * j + e] + m1[4 * j + e]) + sv[e];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int reg = 8 * half + i;
-              const float v = (m0[reg] + m1[reg]) + sv[i];
-              orow[((i & 3) + 8 * (2 * half + (i >> 2))) * C] = v > 0.f ? v : 0.f;
-            }
-          }
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          *(f32x4*)(opx + 8 * j) = v;
         }
       }
       have_prev = true;

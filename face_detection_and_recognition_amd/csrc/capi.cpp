@@ -284,6 +284,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwblock_kernel<%d, %d, %d, %d>", op->Cin, op->H, op->H == 28 ? 7 : op->H, op->H == 7 ? 3 : 1);
       return buf;
     case FP_OP_STEM_U8:
+      if (fp_stem_u8_band_eligible(*op)) return "stem5_u8_band_kernel";
       snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d, true>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
     case FP_OP_YSTEM:

@@ -91,6 +91,7 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
 bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)
 int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stem_u8_shape_ok(const fp_op& op);
+bool fp_stem_u8_band_eligible(const fp_op& op);   // BlazeFace's 5x5 stem on u8 frames, band kernel (canvas rows in an LDS ring)
 int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, int n_ext, hipStream_t s);
 int fp_launch_ystem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 int fp_ystem_nb2(const fp_op& op);

@@ -322,6 +322,9 @@ int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStrea
   return stem_launch<false>(op, a, s);
 }
 
+bool fp_stem_u8_band_eligible(const fp_op& op);
+int fp_launch_stem_u8_band(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, hipStream_t s);
+
 // FP_OP_STEM_U8 (include/facepath.h): the same conv with the H x W input resampled from u8 frames while it is staged.
 bool fp_stem_u8_shape_ok(const fp_op& op) { return op.H + op.W <= 2048 && stem_shape_ok(op, op.H + op.W); }
 
@@ -333,6 +336,7 @@ int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const
   if (ext[e].bytes < (size_t)op.N * fh * fw * 3 || ext[e + 1].bytes < (size_t)(op.H + op.W + 2) * 8 ||
       ext[e + 2].bytes < 256 * sizeof(float) || !ext[e].ptr || !ext[e + 1].ptr || !ext[e + 2].ptr)
     return FP_ERR_BOUNDS;
+  if (fp_stem_u8_band_eligible(op)) return fp_launch_stem_u8_band(op, weights, arena, ext, s);
   StemArgs a;
   stem_fill(op, weights, arena, a);
   a.frames = (const uint8_t*)ext[e].ptr;
@@ -343,4 +347,170 @@ int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const
   a.frame_h = fh;
   a.frame_w = fw;
   return stem_launch<true>(op, a, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BlazeFace's stem on u8 frames, band form (FP_OP_STEM_U8 with KxK = 5x5, OW = 128, Cout = 24, bias + ReLU): the
+// generic kernel above stages the 5 canvas rows of every output row afresh -- with the letterbox fused in, every canvas
+// pixel is RESAMPLED 2.5 times (~70 VALU instructions each, and fp32 MFMAs do not hide VALU work: tools/lab/coexec_lab).
+// Here a workgroup owns a band of R consecutive output rows of one image and keeps the canvas rows in an 8-row LDS ring:
+// output row oy reads ring rows 2oy-1 .. 2oy+3 while the two rows the NEXT output row adds (2oy+4, 2oy+5) are resampled
+// into the ring -- one resample per canvas pixel (+ 3 rows per band), one workgroup barrier per output row.
+//   * wave w owns output pixels 32w .. 32w+31 of the row; the 5x5 weights of its MFMAs live in registers;
+//   * D^T = W^T x A^T (operands swapped), so a lane ends up with 16-byte channel pieces of ITS pixel: bias + ReLU on
+//     float4s, three ds_write_b128 into the wave's private output tile, three coalesced 16-byte global stores;
+//   * same k order (tap pairs 2kq + h, three channels per tap) and the same resampling code as the generic kernel and
+//     the stand-alone letterbox: bit-identical results.
+namespace {
+
+struct StemBandArgs {
+  float* out;
+  const float* w;        // packed [Kpad/4][32][4], Kpad = 104
+  const float* bias;     // [24]
+  const uint8_t* frames;
+  const fp_lb_tap* tabs; // [256] column taps, [256] row taps, trailer, geometry
+  const float* lut;
+  long frame_bytes, row_bytes, out_ns;
+  int frame_h, frame_w, out_rp;   // out_rp: output row pitch in floats ((OW + 1) * 24 row-padded, OW * 24 dense)
+  int R, bands;                   // rows per band, bands per image
+};
+
+constexpr int SB_W = 256, SB_OW = 128, SB_C = 24, SB_WP = 260, SB_KQ = 13;   // ring row: columns -1 .. 258 (zero borders)
+
+__global__ __launch_bounds__(256, 3) void stem5_u8_band_kernel(StemBandArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ring = smem;                                   // [8][SB_WP][4]
+  float* Ot = Ring + 8 * SB_WP * 4;                     // 4 wave tiles [32][24]
+  float* LutS = Ot + 4 * 32 * SB_C;                     // [256]
+  fp_lb_tap* TabS = (fp_lb_tap*)(LutS + 256);           // [512]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+  if (!fp_lb_geometry_ok(p.tabs, SB_W, SB_W, p.frame_h, p.frame_w)) return;   // tables of another geometry (uniform)
+  LutS[tid] = p.lut[tid];
+  for (int i = tid; i < 2 * SB_W; i += 256) TabS[i] = p.tabs[i];
+  const fp_lb_tap tr = p.tabs[2 * SB_W];
+  const int pad_value = tr.a, swap_rb = tr.b;
+  for (int i = tid; i < 8 * SB_WP; i += 256) *(f32x4*)&Ring[i * 4] = z4;       // borders (columns -1, 256 .. 258) stay zero
+
+  // weights of this lane's MFMAs: k-quad 2kq + h (= tap 2kq + h), output channel lr
+  f32x4 wv[SB_KQ];
+#pragma unroll
+  for (int kq = 0; kq < SB_KQ; ++kq) wv[kq] = *(const f32x4*)(p.w + ((kq * 2 + h) * 32 + lr) * 4);
+  f32x4 bias4[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bias4[j] = *(const f32x4*)(p.bias + 8 * j + 4 * h);
+
+  const int img = blockIdx.x / p.bands, band = blockIdx.x - img * p.bands;
+  const int oy0 = band * p.R;
+  const uint8_t* frame = p.frames + (long)img * p.frame_bytes;
+  float* outi = p.out + (long)img * p.out_ns;
+  __syncthreads();
+
+  // canvas row iy (column tid) -> ring: resampled inside the canvas, zero outside it (the conv's F.pad(1, 2, 1, 2))
+  fp_lb_raw raw[2];
+  fp_lb_tap yt[2];
+  const fp_lb_tap xt = TabS[tid];
+  auto issue_rows = [&](int iy0) {          // rows iy0, iy0 + 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = min(max(iy0 + j, 0), SB_W - 1);
+      yt[j] = TabS[SB_W + iy];
+      raw[j] = fp_lb_issue(frame, p.row_bytes, xt, yt[j]);
+    }
+  };
+  auto finish_rows = [&](int iy0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = iy0 + j;
+      const f32x4 v = fp_lb_finish(raw[j], xt, yt[j], LutS, pad_value, swap_rb);
+      *(f32x4*)&Ring[((iy & 7) * SB_WP + 1 + tid) * 4] = (unsigned)iy < (unsigned)SB_W ? v : z4;
+    }
+  };
+  // band prologue: rows 2*oy0 - 1 .. 2*oy0 + 3 (the pair starting at 2*oy0 + 4 belongs to the first step)
+  issue_rows(2 * oy0 - 1);
+  finish_rows(2 * oy0 - 1);
+  issue_rows(2 * oy0 + 1);
+  finish_rows(2 * oy0 + 1);
+  {
+    const int iy = 2 * oy0 + 3, iyc = min(iy, SB_W - 1);
+    yt[0] = TabS[SB_W + iyc];
+    raw[0] = fp_lb_issue(frame, p.row_bytes, xt, yt[0]);
+    const f32x4 v = fp_lb_finish(raw[0], xt, yt[0], LutS, pad_value, swap_rb);
+    *(f32x4*)&Ring[((iy & 7) * SB_WP + 1 + tid) * 4] = iy < SB_W ? v : z4;
+  }
+  __syncthreads();
+
+  float* Ow = Ot + wave * (32 * SB_C);
+  const int px_off = ((wave * 32 + lr) * 2) * 4;        // this lane's output pixel: canvas column 2*ox - 1 -> ring column 2*ox
+  for (int s = 0; s < p.R; ++s) {
+    const int oy = oy0 + s;
+    const int r0 = 2 * oy - 1;                           // first of the 5 canvas rows of this output row
+    const bool more = s + 1 < p.R;
+    if (more) issue_rows(r0 + 5);                        // rows 2oy + 4, 2oy + 5: in flight during the MFMAs
+    int rb[5];                                           // float offsets of ring rows r0 .. r0 + 4 (wave-uniform)
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) rb[ky] = ((r0 + ky) & 7) * (SB_WP * 4);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kq = 0; kq < SB_KQ; ++kq) {
+      // tap 2kq + h (a tap past the 25th meets zero weights: any finite pixel will do -> tap 0)
+      const int t0 = 2 * kq < 25 ? 2 * kq : 0, t1 = 2 * kq + 1 < 25 ? 2 * kq + 1 : 0;
+      const int o0 = rb[t0 / 5] + (t0 % 5) * 4, o1 = rb[t1 / 5] + (t1 % 5) * 4;
+      const f32x4 a = *(const f32x4*)&Ring[(h ? o1 : o0) + px_off];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[kq][e], a[e], acc, 0, 0, 0);
+    }
+    if (more) finish_rows(r0 + 5);                       // other rows than the ones any wave is reading in this step
+    // bias + ReLU on this lane's pixel, channels 8j + 4h .. + 3 -> the wave's tile -> 3 x 16-byte coalesced stores
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = acc[4 * j + e] + bias4[j][e];
+        v[e] = x > 0.f ? x : 0.f;
+      }
+      *(f32x4*)&Ow[lr * SB_C + 8 * j + 4 * h] = v;
+    }
+    float* orow = outi + (long)oy * p.out_rp + wave * (32 * SB_C);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *(f32x4*)(orow + (lane + 64 * j) * 4) = *(const f32x4*)&Ow[(lane + 64 * j) * 4];
+    __syncthreads();                                     // the next step reads the rows just written
+  }
+}
+
+}  // namespace
+
+bool fp_stem_u8_band_eligible(const fp_op& op) {
+  return op.kind == FP_OP_STEM_U8 && op.KH == 5 && op.KW == 5 && op.stride == 2 && op.pad_t == 1 && op.pad_l == 1 &&
+         op.H == SB_W && op.W == SB_W && op.OH == SB_OW && op.OW == SB_OW && op.Cout == SB_C && op.out_ld == SB_C &&
+         op.scale_off < 0 && op.bias_off >= 0 && op.act == FP_ACT_RELU && op.res_mode == FP_RES_NONE && op.N >= 16;
+}
+
+int fp_launch_stem_u8_band(const fp_op& op, const float* weights, float* arena, const fp_ext* ext, hipStream_t s) {
+  const long e = op.in_off;
+  StemBandArgs a;
+  a.out = arena + op.out_off;
+  a.w = weights + op.w_off;
+  a.bias = weights + op.bias_off;
+  a.frames = (const uint8_t*)ext[e].ptr;
+  a.tabs = (const fp_lb_tap*)ext[e + 1].ptr;
+  a.lut = (const float*)ext[e + 2].ptr;
+  a.frame_h = op.res_H;
+  a.frame_w = op.res_W;
+  a.row_bytes = (long)op.res_W * 3;
+  a.frame_bytes = (long)op.res_H * op.res_W * 3;
+  a.out_ns = op.out_ns;
+  a.out_rp = ((op.flags & FP_OPF_OUT_ROWPAD) ? SB_OW + 1 : SB_OW) * SB_C;
+  a.R = 16;
+  a.bands = SB_OW / a.R;
+  const size_t lds = 4 * ((size_t)8 * SB_WP * 4 + 4 * 32 * SB_C + 256) + 8 * (size_t)(2 * SB_W);
+  hipLaunchKernelGGL(stem5_u8_band_kernel, dim3(op.N * a.bands), dim3(256), lds, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
 }

@@ -101,15 +101,16 @@ def test_blazeface_fused_and_unfused_plans_agree(dev, back):
     assert rel_err(outs[True][0], outs[False][0]) < 1e-5
 
 
-@pytest.mark.parametrize("back,frame_hw", [(True, (576, 1024)), (False, (576, 1024)), (True, (97, 33)), (True, (300, 211)),
-                                           (False, (1275, 1650))])
-def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw):
+@pytest.mark.parametrize("back,frame_hw,nf", [(True, (576, 1024), 5), (False, (576, 1024), 5), (True, (97, 33), 5),
+                                              (True, (300, 211), 5), (False, (1275, 1650), 5),
+                                              (True, (576, 1024), 21), (True, (211, 300), 16)])   # >= 16 frames: stem5_u8_band_kernel
+def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw, nf):
     """FP_OP_STEM_U8 (the 5x5 stem resamples the u8 frames through fp_letterbox_tables while it stages its input;
     no fp32 canvas) against the stand-alone letterbox kernel + the fp32 stem: identical raw network outputs."""
     from face_detection_and_recognition_amd.modules.blazeface import blazeface as B
     from face_detection_and_recognition_amd.modules.blazeface.model import BlazeFaceModel
     rng = np.random.default_rng(frame_hw[1])
-    frames = torch.from_numpy(rng.integers(0, 256, (5,) + frame_hw + (3,), dtype=np.uint8)).to(dev)
+    frames = torch.from_numpy(rng.integers(0, 256, (nf,) + frame_hw + (3,), dtype=np.uint8)).to(dev)
     net = BlazeFace(back)
     net.load_state_dict(synth_state_dict(net.state_dict(), 100 + int(back), residual_gain=0.5))
     net = net.to(dev)
@@ -122,8 +123,9 @@ def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw):
             model.raw_batch(frames)
             torch.cuda.synchronize()
             assert (net.last_plan.input is None) == flag
-            assert net.last_plan.kernel_name(0).startswith("stem_conv_kernel<5, 1, " + ("true" if flag else "false")) or \
-                not flag
+            if flag:
+                assert net.last_plan.kernel_name(0) == ("stem5_u8_band_kernel" if back and nf >= 16 else
+                                                        "stem_conv_kernel<5, 1, true>")
             outs[flag] = (net.last_plan.r.clone().cpu().numpy(), net.last_plan.c.clone().cpu().numpy())
         finally:
             B.BlazeFace.FUSE_LETTERBOX = True
@@ -1187,7 +1189,7 @@ def test_full_size_config1_step_sampled_frames_vs_oracle(dev):
     plan = pipe.emb_plan
     assert plan.N % 256 == 0 and plan.N >= n and L.OP_DWBLOCK in [plan.ops[i].kind for i in range(plan.n_ops)]
     names = [det.net.last_plan.kernel_name(i) for i in range(det.net.last_plan.n_ops)]
-    assert names[0].startswith("stem_conv_kernel<5, 1, true>") and names.count("blazepair_kernel<128>") == 3
+    assert names[0] == "stem5_u8_band_kernel" and names.count("blazepair_kernel<128>") == 3
     e = out["emb"].cpu().numpy()
     info = out["info"].cpu().numpy()
     np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)
