@@ -166,31 +166,30 @@ def run_pipeline(args):
     emb = W.build_embedder(dev)
     ref = W.make_reference(N_REF, dev)
     pipe = FacePipeline(det, emb, ref, tau=0.3)
-    gather_block = n_dev = None
+    exchange = None
     multi = dist is not None
     if multi:
+        # The step's exchange (all_gather of the embedding blocks + counts, cross-rank cosine match) runs on a side stream
+        # BESIDE the next step's detector and is consumed one step late (distributed.StepExchange): ranks meet inside a
+        # collective only when one of them is a whole step ahead, instead of in every step.
         from face_detection_and_recognition_amd import distributed as D
-        gather_block = torch.zeros((EMB_CAP_ROWS, emb.embedding_size), device=dev)
-        n_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
+        if backend == "nccl":               # RCCL over xGMI + the HIP cosine kernel on the gathered matrix
+            exchange = D.StepExchange(EMB_CAP_ROWS, emb.embedding_size, dev, pipe.tau,
+                                      lambda G, R, tau, rinv: S.cosine_filter(G, R, tau, rinv=rinv), S.row_inv_norm)
+        else:                               # gloo rehearsal: collectives on host copies, kernel on the device
+            exchange = D.StepExchange(EMB_CAP_ROWS, emb.embedding_size, dev, pipe.tau,
+                                      lambda G, R, tau, rinv: S.cosine_filter(G.to(dev), R.to(dev), tau, rinv=rinv.to(dev)),
+                                      lambda R: S.row_inv_norm(R.to(dev)).cpu(), comm=lambda t: t.cpu())
 
-    def to_comm(t):
-        return t if backend == "nccl" else t.cpu()
+    matched = [0]
 
     def step(k):
         out = pipe.step(batches[k % N_BATCHES])
         n = out["n_faces"]
         if multi:
-            if n > EMB_CAP_ROWS:
-                raise RuntimeError(f"{n} faces in one step exceed the all_gather block of {EMB_CAP_ROWS} rows")
-            gather_block[:n].copy_(out["emb"])
-            n_dev.fill_(n)
-            if backend == "nccl":           # RCCL over xGMI + the HIP cosine kernel on the gathered matrix
-                D.cross_rank_match(gather_block, n_dev, pipe.tau,
-                                   lambda G, R, tau, rinv: S.cosine_filter(G, R, tau, rinv=rinv), S.row_inv_norm)
-            else:                           # gloo rehearsal: collectives on host copies, kernel on the device
-                D.cross_rank_match(to_comm(gather_block), to_comm(n_dev), pipe.tau,
-                                   lambda G, R, tau, rinv: S.cosine_filter(G.to(dev), R.to(dev), tau, rinv=rinv.to(dev)),
-                                   lambda R: S.row_inv_norm(R.to(dev)).cpu())
+            prev = exchange.submit(out["emb"], n)       # result of step k - 1's exchange (None on the first step)
+            if prev is not None:
+                matched[0] += 1
         return n
 
     nf_warm = []
@@ -235,6 +234,8 @@ def run_pipeline(args):
         n = step(k)
         faces += n
         faces_per_step.append(n)
+    if multi:
+        exchange.drain()                                 # the last step's exchange belongs to the timed region
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -320,7 +321,8 @@ def run_pipeline(args):
                        "weights": "seeded synthetic (no weights ship with the reference)",
                        "parallelism": f"frames sharded by image, {world} rank(s), 1 per GPU" +
                                       (f", all_gather of the step's embeddings over "
-                                       f"{'RCCL' if backend == 'nccl' else backend + ' (CPU rehearsal)'} + cross-rank cosine match"
+                                       f"{'RCCL' if backend == 'nccl' else backend + ' (CPU rehearsal)'} + cross-rank cosine match, "
+                                       f"overlapped with the next step's detector (side stream, consumed one step late)"
                                        if world > 1 else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -73,12 +73,75 @@ def cross_rank_match(block, n_valid, tau, filter_fn, inv_norm_fn, group=None):
     others = valid.clone()
     others[rank * cap:(rank + 1) * cap] = False
     rinv = inv_norm_fn(rows) * others.to(rows.dtype)
-    best, arg, keep = filter_fn(block, rows, tau, rinv)
+    best, arg, keep = (t.to(others.device) for t in filter_fn(block, rows, tau, rinv))   # (a rehearsal's kernel may run elsewhere)
     hit = others[arg.long().clamp_(0, others.shape[0] - 1)]          # did the maximum land on a real peer row?
     arg = torch.where(hit, arg, torch.full_like(arg, -1))
     best = torch.where(hit, best, torch.full_like(best, -1.0))
     keep = keep & hit
     return best, arg, keep, counts
+
+
+class StepExchange:
+    """cross_rank_match of step k running BESIDE step k + 1's detector: the exchange is issued on a side stream (the
+    collectives of torch's NCCL / RCCL backend follow the stream that is current when they are called) behind an event
+    on the step's embeddings, and its result is handed out one step late.  Without it every rank waits for the slowest
+    rank's embeddings inside every step; with it a rank only waits when it is a whole step ahead.  Two buffer sets, so
+    step k + 2 reuses the block of step k only after that exchange has finished (event wait on the main stream).
+    On a CPU process group (gloo tests) there are no streams: the exchange runs in place, the hand-out order is the
+    same."""
+
+    def __init__(self, cap, dim, device, tau, filter_fn, inv_norm_fn, group=None, comm=lambda t: t):
+        self.tau, self.filter_fn, self.inv_norm_fn, self.group, self.comm = tau, filter_fn, inv_norm_fn, group, comm
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.blocks = [torch.zeros((cap, dim), device=self.device) for _ in range(2)]
+        self.counts = [torch.zeros((1,), dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.done = [torch.cuda.Event() if self.cuda else None for _ in range(2)]
+        self.results = [None, None]
+        self.k = 0
+
+    def submit(self, emb, n):
+        """Queue the exchange of this step's embeddings (emb: (n, dim) on `device`).  Returns the result of the PREVIOUS
+        step's exchange -- (best, arg, keep, counts), ready for use on the current stream -- or None on the first step."""
+        slot = self.k & 1
+        self.k += 1
+        cap = self.blocks[slot].shape[0]
+        if n > cap:
+            raise RuntimeError(f"{n} faces in one step exceed the exchange block of {cap} rows")
+        if self.cuda:
+            main = torch.cuda.current_stream(self.device)
+            if self.results[slot] is not None:
+                main.wait_event(self.done[slot])           # the exchange that last used this slot (two steps ago)
+            self.blocks[slot][:n].copy_(emb)
+            self.counts[slot].fill_(n)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                self.results[slot] = cross_rank_match(self.comm(self.blocks[slot]), self.comm(self.counts[slot]), self.tau,
+                                                      self.filter_fn, self.inv_norm_fn, self.group)
+                self.done[slot].record(self.stream)
+        else:
+            self.blocks[slot][:n].copy_(emb)
+            self.counts[slot].fill_(n)
+            self.results[slot] = cross_rank_match(self.comm(self.blocks[slot]), self.comm(self.counts[slot]), self.tau,
+                                                  self.filter_fn, self.inv_norm_fn, self.group)
+        return self._take(slot ^ 1) if self.k > 1 else None
+
+    def _take(self, slot):
+        res = self.results[slot]
+        if res is not None and self.cuda:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(self.done[slot])
+            for t in res:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(main)                  # produced on the side stream, consumed here
+        return res
+
+    def drain(self):
+        """The result of the last submitted step (call once after the final submit; makes the current stream wait)."""
+        return self._take((self.k - 1) & 1) if self.k else None
 
 
 def sharded_cosine_filter(local_gallery, local_reference, tau, filter_fn, group=None, equal_blocks=False):

@@ -88,6 +88,25 @@ def _worker(rank, world, port, q):
     b5, a5, k5, c5 = D.cross_rank_match(torch.from_numpy(block), torch.tensor([n5]), -0.5, filter_rinv, inv_norm)
     if rank == 0:      # no peer rows: nothing can match, whatever tau is
         ok = ok and c5.tolist() == [5, 0] and (a5.numpy()[:5] == -1).all() and not k5.numpy()[:5].any()
+    # the overlapped form (bench.py N > 1): StepExchange hands step k's result out while step k + 1 is submitted; same
+    # numbers as the in-step exchange, one step late, block reuse after two steps
+    ex = D.StepExchange(cap, D_, "cpu", 0.1, filter_rinv, inv_norm)
+    steps = []
+    for k in range(4):
+        nk = [5 + 3 * k, 11 - 2 * k][rank]
+        ek = torch.from_numpy(rng.normal(0, 1, (20, D_)).astype(np.float32)[:nk] + (0.5 if rank else -0.25) * k)
+        blk_k = torch.zeros((cap, D_))
+        blk_k[:nk] = ek
+        want = D.cross_rank_match(blk_k, torch.tensor([nk]), 0.1, filter_rinv, inv_norm)
+        got = ex.submit(ek, nk)
+        steps.append((want, nk))
+        if k == 0:
+            ok = ok and got is None
+        else:
+            prev, npv = steps[k - 1]       # rows past the step's face count are padding (stale rows of the reused block)
+            ok = ok and all(torch.equal(a[:npv], b[:npv]) for a, b in zip(got[:3], prev[:3])) and torch.equal(got[3], prev[3])
+    last = ex.drain()
+    ok = ok and all(torch.equal(a[:steps[-1][1]], b[:steps[-1][1]]) for a, b in zip(last[:3], steps[-1][0][:3]))
     rows_g, valid_g, _ = D.all_gather_blocks(torch.from_numpy(block), torch.tensor([n_loc]))
     ok = ok and valid_g.tolist() == [i < 17 for i in range(cap)] + [i < 9 for i in range(cap)]
     mean = D.sharded_l2_mean(torch.from_numpy(R[r0:r1]))
