@@ -90,14 +90,14 @@ class Depth_Wise(_NoCompute):
 
     @staticmethod
     def block_policy(n):
-        """Map sizes (14, 7; 28 never) on which the whole-block kernel beats the two-launch form at batch n, from
-        the measured costs on MI355X (profiles/r03_mfn_probe.log, tools/lab/dwblock_lab): the block kernel runs one
-        tile per CU at a time (14x14: one image, 84 us per round of 256 tiles; 7x7: three images, 66 us per round), the
-        pair scales with n (14x14: 0.348 us per image; 7x7: 33 us + 0.094 us per image).  At the bench's ~528 faces the
-        14x14 blocks would need a third, nearly empty round (239 us against 184), so only the 7x7 blocks take it."""
+        """Map sizes on which the whole-block kernel beats the two-launch form at batch n, from whole-network A/B runs
+        on MI355X (tools/mfn_probe.py, profiles/r03_mfn_probe.log): only the 7x7 blocks, when their tiles (three images
+        each, one tile per CU at a time, ~66 us per round of 256 tiles) fill one round well: 33 us per forward at 528
+        crops.  The 14x14 blocks never: a tile is a whole image, so ~528 crops need a third, nearly empty round (239 us
+        against 184), and even at 1024 crops (4 full rounds) the six kernels run 320-377 us in the network (315 in
+        isolation: the clock they reach after 2 ms of back-to-back launches) against 360 for the pair; 28x28 never
+        (7-row bands recompute 2 of 9 expand rows)."""
         shapes = []
-        if n >= 256 and -(-n // 256) * 84.0 < 0.348 * n:
-            shapes.append(14)
         if n >= 192 and -(-(-(-n // 3)) // 256) * 66.0 < 33.0 + 0.094 * n:
             shapes.append(7)
         return tuple(shapes)

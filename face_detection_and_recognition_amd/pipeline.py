@@ -95,6 +95,49 @@ class FacePipeline:
         cap, n_pad = self.emb_key
         return self.emb.plan_for(cap, n_run=n_pad)
 
+    # -- software-pipelined form ----------------------------------------------------------------------
+    def step_overlapped(self, frames):
+        """step() with the host round trip taken off the GPU's critical path: this call ENQUEUES the detector stages of
+        `frames` and then finishes the PREVIOUS call's batch (embed + filter), whose face count -- produced a whole
+        detector pass ago -- is already on the host when it is read (pinned buffer + event).  The GPU queue never drains
+        while the host waits.  Returns the previous batch's result dict (None on the first call); flush() returns the
+        last one.  Same kernels, same numbers as step(); a detector overflow (more survivors than the cap in some frame)
+        falls back to the exact un-capped re-run for that batch."""
+        dets, counts, over = self.detect(frames)
+        items, info, nf = self.crops(frames, dets, counts)
+        host = torch.empty((2,), dtype=torch.int32).pin_memory()
+        both = nf if over is None else torch.stack([nf[0], over.sum().to(torch.int32)])
+        host[:both.numel()].copy_(both, non_blocking=True)
+        if over is None:
+            host[1] = 0
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        prev, self._pending = getattr(self, "_pending", None), (frames, items, info, host, ev)
+        return None if prev is None else self._finish(prev)
+
+    def flush(self):
+        """Finish the batch a previous step_overlapped() call left pending (None if there is none)."""
+        prev, self._pending = getattr(self, "_pending", None), None
+        return None if prev is None else self._finish(prev)
+
+    def _finish(self, pending):
+        frames, items, info, host, ev = pending
+        ev.synchronize()
+        n, n_over = int(host[0]), int(host[1])
+        if n_over:                              # > MAX_DET survivors in some frame: exact re-run without a cap
+            dets, counts, _ = self.detect(frames, max_det=None)
+            items, info, nf = self.crops(frames, dets, counts)
+            n = int(nf.item())
+        cap = items.shape[0]
+        if n > cap:
+            raise L.FacepathError(f"{n} faces in the batch exceed max_faces_per_frame*B = {cap}")
+        emb = self.embed(frames, items, n)
+        res = self.filter(emb)
+        out = dict(n_faces=n, info=info[:n], emb=emb.clone(), items=items[:n])
+        if res is not None:
+            out.update(best=res[0], arg=res[1], keep=res[2])
+        return out
+
     def filter(self, emb):
         if self.reference is None or emb.shape[0] == 0:
             return None

@@ -18,8 +18,9 @@ def main():
     for n in ns:
         plans = {}
         x = torch.randn((n, 112, 112, 4), device=dev)
-        for fb in (True, False):
-            plans[fb] = emb._build(n, block_shapes=(14, 7) if fb else ())
+        variants = {True: (14, 7), False: (), "14": (14,), "7": (7,)}
+        for fb, shapes in variants.items():
+            plans[fb] = emb._build(n, block_shapes=shapes)
             plans[fb].input.copy_(x)
         for rep in range(2):
             for fb in (True, False):
@@ -29,7 +30,7 @@ def main():
                     for _ in range(3):
                         plans[fb].run()
         # end-to-end wall per forward, interleaved
-        for fb in (True, False):
+        for fb in (True, False, "14", "7", True, False):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
