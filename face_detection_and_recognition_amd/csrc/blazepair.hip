@@ -15,7 +15,7 @@
 //   * the shortcut + bias of block 1 are parked in the ring slot the row will occupy, and the epilogue updates them in
 //     place, so there is no shortcut tile; block 2's output tile reuses the A tile: 66 KiB of LDS per workgroup, two
 //     workgroups per CU;
-//   * a band needs y1 rows y0 - 1 .. y0 + R: R + 2 block-1 rows for R output rows (R = 32: 6 % recomputed).
+//   * a band needs y1 rows y0 - 1 .. y0 + R: R + 2 block-1 rows for R output rows (R = 64: 3 % recomputed).
 // Bytes per pair: x once (+ the band halos) and y2 once -- half of what two launches move; the instruction count per
 // pixel is the same as two blazeblock_wp launches (fp32 MFMAs and VALU share the SIMD's ALU: tools/lab/coexec_lab.hip).
 #include "common.h"
@@ -279,11 +279,15 @@ int launch_pair(const BlazePairArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Rows per band: the largest divisor of H that is <= 32 and leaves at least 512 workgroups (two per CU), never below 8.
+// Rows per band: the largest divisor of H that is <= 64 and leaves at least 512 workgroups (two per CU), never below 8
+// (batch 256 at 128 x 128: 64-row bands = 512 workgroups, 3 % of block 1 recomputed: 255 us against 269 with 32-row bands).
+#ifndef FP_PAIR_MAX_ROWS
+#define FP_PAIR_MAX_ROWS 64
+#endif
 int fp_blazepair_band_rows(const fp_op& op) {
   const int nsub = 4 / (op.W / 32);
   int best = 0;
-  for (int r = 8; r <= 32 && r <= op.H; r += 4) {
+  for (int r = 8; r <= FP_PAIR_MAX_ROWS && r <= op.H; r += 4) {
     if (op.H % r) continue;
     if (best == 0 || (long)op.N * (op.H / r) / nsub >= 512) best = r;
   }
