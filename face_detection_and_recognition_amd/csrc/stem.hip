@@ -507,7 +507,10 @@ int fp_launch_stem_u8_band(const fp_op& op, const float* weights, float* arena, 
   a.frame_bytes = (long)op.res_H * op.res_W * 3;
   a.out_ns = op.out_ns;
   a.out_rp = ((op.flags & FP_OPF_OUT_ROWPAD) ? SB_OW + 1 : SB_OW) * SB_C;
-  a.R = 16;
+#ifndef FP_STEM_BAND_ROWS
+#define FP_STEM_BAND_ROWS 16
+#endif
+  a.R = FP_STEM_BAND_ROWS;
   a.bands = SB_OW / a.R;
   const size_t lds = 4 * ((size_t)8 * SB_WP * 4 + 4 * 32 * SB_C + 256) + 8 * (size_t)(2 * SB_W);
   hipLaunchKernelGGL(stem5_u8_band_kernel, dim3(op.N * a.bands), dim3(256), lds, s, a);
