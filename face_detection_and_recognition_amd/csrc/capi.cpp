@@ -80,7 +80,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
-  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3)) return FP_ERR_INVALID_ARG;
+  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3)) return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
     return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
@@ -166,10 +167,13 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.kind == FP_OP_DWBLOCK) {
     // w_off: expand packed as CONV (K = Cin, Npad = Cmid); scale_off: [15][Cmid]; slope_off: project packed as CONV
     // (K = Cmid, Npad = Cout) + [Cout] scale + [Cout] bias.  The shapes the kernel exists for are fp_dwblock_supported's.
-    if (!fp_dwblock_supported(op)) return FP_ERR_UNSUPPORTED;
-    if (!span_ok(op.w_off, (int64_t)op.Cin * op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
+    // FP_OPF_SPLIT3: both weight matrices as three bf16 planes (1.5 floats per weight), see facepath.h
+    const bool x6 = (op.flags & FP_OPF_SPLIT3) != 0;
+    if (!(x6 ? fp_dwblock_x6_supported(op) : fp_dwblock_supported(op))) return FP_ERR_UNSUPPORTED;
+    if (!span_ok(op.w_off, x6 ? fp_dwblock_x6_we_floats(op) : (int64_t)op.Cin * op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
     if (!span_ok(op.scale_off, 15 * (int64_t)op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
-    if (!span_ok(op.slope_off, (int64_t)op.Cmid * op.Cout + 2 * (int64_t)op.Cout, weight_floats)) return FP_ERR_BOUNDS;
+    if (!span_ok(op.slope_off, x6 ? fp_dwblock_x6_wp_floats(op) : (int64_t)op.Cmid * op.Cout + 2 * (int64_t)op.Cout, weight_floats))
+      return FP_ERR_BOUNDS;
   }
   if (op.kind == FP_OP_YSTEM || op.kind == FP_OP_YSTEM_U8) {
     if (op.Cin != (ext_in ? 3 : 4) || op.res_C <= 0 || op.res_C > 32 || op.Cout > 32) return FP_ERR_UNSUPPORTED;
@@ -281,6 +285,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "blazepair_kernel<%d>", op->W);
       return buf;
     case FP_OP_DWBLOCK:
+      if (op->flags & FP_OPF_SPLIT3) { snprintf(buf, sizeof(buf), "dwblock_x6_kernel<%d, %d>", op->Cin, op->H); return buf; }
       snprintf(buf, sizeof(buf), "dwblock_kernel<%d, %d, %d, %d>", op->Cin, op->H, op->H == 28 ? 7 : op->H, op->H == 7 ? 3 : 1);
       return buf;
     case FP_OP_STEM_U8:
@@ -314,7 +319,8 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_L2NORM: return fp_launch_l2norm(op, arena, s);
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
     case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
-    case FP_OP_DWBLOCK: return fp_launch_dwblock(op, weights, arena, s);
+    case FP_OP_DWBLOCK:
+      return (op.flags & FP_OPF_SPLIT3) ? fp_launch_dwblock_x6(op, weights, arena, s) : fp_launch_dwblock(op, weights, arena, s);
     case FP_OP_BLAZEPAIR: return fp_launch_blazepair(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);

@@ -1,0 +1,423 @@
+// dwblockx6.hip — a whole stride-1 Mobile-FaceNet Depth_Wise block on the bf16 matrix cores with fp32-equivalent
+// arithmetic (split.h: exact three-way operand split, six products, fp32 accumulation) — gfx950.
+//
+// Depth_Wise.forward (fde/modules/mobile_facenet/mobile_facenet.py:77-88):
+//     conv (1x1 expand C -> G, BN, PReLU) -> conv_dw (3x3 depthwise, BN, PReLU) -> project (1x1 G -> C, BN) [+ x].
+// dwblock.hip (fp32 MFMA) showed that the fused block is bound by vector-ALU issue: the fp32 MFMA IS a vector-ALU
+// instruction (DESIGN finding 18).  Here both 1x1 convs run on v_mfma_f32_16x16x32_bf16, the depthwise conv and the
+// operand split run on the VALU beside them, and the expanded tensor still never leaves the CU.
+//
+//   tile      = 7 output rows of one image (14x14: two bands, 28x28: four) = one 256-thread workgroup; two workgroups
+//               per CU (<= 76 KiB of LDS each), so one's VALU phase runs under the other's MFMA phase without any
+//               software pipelining inside a workgroup.
+//   x         = the band's input rows (+ the halo row above / below, whose expand values are recomputed: 8 rows for 7
+//               at 14x14, 9 at 28x28) are loaded ONCE, split into three bf16 planes and kept in registers as the
+//               activation fragments of the expand GEMM: wave w owns the 16-pixel tiles w, w + 4, ...
+//   round     = 32 expanded channels:
+//       E   W_e^T (LDS, three bf16 planes, staged by LDS-DMA) x x^T (registers) -> BN + PReLU -> E-image (fp32,
+//           row-padded: zero pixel after every row, zero rows outside the image).  The operands are swapped
+//           (D^T = W^T X^T), so a lane holds four consecutive channels of ONE pixel: 16-byte LDS writes.
+//       D   3x3 depthwise + BN + PReLU on the VALU (a lane = channel pair x column, marching down the rows with the
+//           window in registers), result split into bf16 planes -> D-tile [3][pixels][32]
+//       P   W_p^T (registers, prefetched during D) x D^T -> output tile in registers (wave w owns C / 4 output channels)
+//     two workgroup barriers per round (three more at 28x28, where D / P run in two row chunks to keep LDS <= 80 KiB).
+//   epilogue  = BN affine + x, 16-byte loads / stores straight from the accumulators.
+//
+// Traffic per tile: x once (+ halo rows), y once, weights from L2 (the split weights are 1.5x the fp32 ones).
+// MFMA work per 14x14 block: 2 bands x 8 rounds x (7 x 2 x 4 + 7 x 8) tile-slabs x 6 = 10.7 k MFMAs of 16 cycles per
+// image against 25 k of 32 cycles for dwblock.hip.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "split.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_ptr;
+
+struct DwbX6Args {
+  const float* in;
+  float* out;
+  const unsigned short* we;   // expand weights, split: [R][3][C/32][32 g][32 k] bf16
+  const float* par;           // [15][G]: expand scale, bias, slope; 9 depthwise taps; depthwise scale, bias, slope
+  const unsigned short* wp;   // project weights, split: [R][3][C co][32 g] bf16
+  const float* paff;          // [C] project BN scale, [C] bias
+  int N, has_res;
+#ifdef FP_X6_STAMPS
+  unsigned long long* stamps;   // lab builds only (tools/lab/x6_lab.hip): s_memtime per phase, [block < 4][wave][round][8]
+#endif
+  int stagger;   // lab knob (FP_X6_STAGGER): units of 1024 cycles the second workgroup of a CU waits before its first round
+};
+
+#ifdef FP_X6_STAMPS
+#define X6_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (p.stamps && blockIdx.x < 4 && (threadIdx.x & 63) == 0) {                                      \
+      unsigned long long tt_;                                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");                     \
+      p.stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 9 + s) * 8 + (k)] = tt_;                      \
+    }                                                                                                 \
+  } while (0)
+#else
+#define X6_STAMP(k) do { } while (0)
+#endif
+
+template <int C, int HW>
+struct X6Cfg {
+  static_assert((C == 128 && HW == 14) || (C == 64 && HW == 28), "");
+  static constexpr int RB = 7;                           // output rows of a tile
+  static constexpr int G = 2 * C, KCH = 32, R = G / KCH, KS = C / 32;
+  static constexpr int NBAND = HW / RB;
+  static constexpr int ERMAX = NBAND == 2 ? RB + 1 : RB + 2;   // computed expand rows of a band, at most
+  static constexpr int EPX = ERMAX * HW;
+  static constexpr int MTE = (EPX + 15) / 16;
+  static constexpr int NOWN = (MTE + 3) / 4;             // 16-pixel tiles of x a wave owns (w, w + 4, ...)
+  static constexpr int ROWP = HW + 1;                    // slots per E-image row (one zero pad pixel)
+  static constexpr int NSLOT = (RB + 2) * ROWP + 1;      // + the leading pad pixel; slot NSLOT swallows junk rows
+  static constexpr int LDE = 36;                         // floats per slot (odd number of 16-byte units)
+  static constexpr int EB = (NSLOT + 1) * LDE;           // floats
+  static constexpr int NCHUNK = HW == 28 ? 2 : 1;        // D / P row chunks
+  static constexpr int crow0(int c) { return c == 0 ? 0 : 4; }
+  static constexpr int crows(int c) { return NCHUNK == 1 ? RB : (c == 0 ? 4 : 3); }
+  static constexpr int mtc(int c) { return (crows(c) * HW + 15) / 16; }
+  static constexpr int tbase(int c) { return c == 0 ? 0 : mtc(0); }
+  static constexpr int MTP = NCHUNK == 1 ? mtc(0) : mtc(0) + mtc(1);
+  static constexpr int DPL = mtc(0) * 16 * 32;           // bf16 elements per plane of the D tile (largest chunk)
+  static constexpr int WL = 3 * KS * 32 * 32;            // bf16 elements of a round's expand weights
+  static constexpr int PL = 15 * KCH;                    // floats of a round's parameters
+  static constexpr int NCT = C / 64;                     // 16-channel output tiles per wave
+  static constexpr int NPASS = (HW + 15) / 16;           // depthwise passes over the columns
+  static constexpr int LDS_BYTES = EB * 4 + 3 * DPL * 2 + WL * 2 + 2 * PL * 4;
+  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  static_assert(MTE <= 4 * NOWN && NOWN % 2 == 0 && (WL * 2) % 4096 == 0, "");
+};
+
+template <int C, int HW>
+__global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
+  using K = X6Cfg<C, HW>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* El = (float*)smem_raw;                                        // [NSLOT + 1][LDE]
+  unsigned short* Dl = (unsigned short*)(smem_raw + K::EB * 4);        // [3][DPL]
+  unsigned short* Wl = Dl + 3 * K::DPL;                                // [3][KS][32][32]
+  float* Pl = (float*)(Wl + K::WL);                                    // [2][15][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int img = tile / K::NBAND;
+  const int r0 = (tile % K::NBAND) * K::RB;
+  const int elo = r0 > 0 ? r0 - 1 : 0;                                 // first / last computed expand row
+  const int ehi = r0 + K::RB < HW ? r0 + K::RB : HW - 1;
+  const int epx = (ehi - elo + 1) * HW;                                // computed expand pixels of this band
+  const int vr0 = r0 > 0 ? 0 : 1;                                      // E-image row of expand row elo
+  constexpr int G = K::G, R = K::R, KS = K::KS;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const float* xin = p.in + (long)img * (HW * HW * C);
+  float* yout = p.out + (long)img * (HW * HW * C);
+
+  // ---- staging: a round's expand weights (LDS-DMA, 1 KiB per wave and instruction) and parameters ----
+  auto stage = [&](int s) {
+    const unsigned char* src = (const unsigned char*)p.we + (long)s * (K::WL * 2) + lane * 16;
+#pragma unroll
+    for (int j = 0; j < K::WL * 2 / 4096; ++j) {
+      const int chunk = j * 4 + wave;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(src + chunk * 1024), (lds_ptr)((unsigned char*)Wl + chunk * 1024), 16, 0, 0);
+    }
+    if (wave < 2 && tid < 15 * 8) {
+      const float* ps = p.par + K::KCH * s + ((tid >> 3) * G + 4 * (tid & 7));
+      __builtin_amdgcn_global_load_lds((gbl_ptr)ps, (lds_ptr)(Pl + (s & 1) * K::PL + wave * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue ----
+  stage(0);
+  for (int i = tid; i < K::EB / 4; i += 256) *(f32x4*)&El[i * 4] = z;
+  // x -> registers as split fragments: lane = (pixel l15 of the tile, k group q): k = 32 ks + 8 q .. + 7
+  fp_frag3 xf[K::NOWN][KS];
+  int eoff[K::NOWN];   // float offset of this lane's pixel of each owned tile in the E-image (+ 4 q)
+#pragma unroll
+  for (int t = 0; t < K::NOWN; ++t) {
+    const int m = wave + 4 * t;
+    const int e = 16 * m + l15;
+    const int ec_ = min(e, epx - 1);
+    const float* src = xin + (elo * HW + ec_) * C + 8 * q;
+    f32x4 lo[KS], hi[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      lo[ks] = *(const f32x4*)(src + 32 * ks);
+      hi[ks] = *(const f32x4*)(src + 32 * ks + 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[t][ks] = fp_split8(lo[ks], hi[ks]);
+    const int er = ec_ / HW, ecol = ec_ - er * HW;
+    const int slot = e < epx ? (vr0 + er) * K::ROWP + ecol + 1 : K::NSLOT;
+    eoff[t] = slot * K::LDE + 4 * q;
+  }
+  // output tile of this wave: [pixel tile][channel tile], lane = (pixel l15, channels 16 ct + 4 q .. + 3)
+  f32x4 pacc[K::MTP][K::NCT];
+#pragma unroll
+  for (int t = 0; t < K::MTP; ++t)
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j) pacc[t][j] = z;
+
+  // project weights of a round: this wave's channel tiles, k = 32 s + 8 q .. + 7
+  fp_frag3 pbw[K::NCT];
+  auto load_pbw = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j)
+    {
+      const unsigned short* src = p.wp + ((long)(s * 3 * C + 16 * (wave * K::NCT + j) + l15) * 32 + 8 * q);
+      pbw[j].h = *(const u32x4*)src;
+      pbw[j].m = *(const u32x4*)(src + C * 32);
+      pbw[j].l = *(const u32x4*)(src + 2 * C * 32);
+    }
+  };
+
+  // E(s): expand round s -> E-image.  Straight-line: a wave whose last owned tile does not exist (m >= MTE) computes it
+  // on clamped pixels and drops it into the junk slot -- a wave-uniform branch around every MFMA group keeps hipcc from
+  // moving the next group's LDS reads above this group's MFMAs.  The weight fragments of group g + 1 are requested
+  // before the MFMAs of group g.
+  auto expand = [&](int s) {
+    const float* Pc = Pl + (s & 1) * K::PL;
+    f32x4 acc[K::NOWN][2];
+#pragma unroll
+    for (int t = 0; t < K::NOWN; ++t) acc[t][0] = acc[t][1] = z;
+    u32x4 wf[2][3];
+    auto ldw = [&](int g, u32x4* w) {
+      const int ks = g >> 1, nt = g & 1;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w[pl] = *(const u32x4*)(Wl + (((pl * KS + ks) * 32 + 16 * nt + l15) * 32 + 8 * q));
+    };
+    ldw(0, wf[0]);
+#pragma unroll
+    for (int g = 0; g < 2 * KS; ++g) {
+      if (g + 1 < 2 * KS) ldw(g + 1, wf[(g + 1) & 1]);
+      const int ks = g >> 1, nt = g & 1;
+#pragma unroll
+      for (int t = 0; t < K::NOWN; t += 2)
+        fp_mfma_x6_2b(wf[g & 1][0], wf[g & 1][1], wf[g & 1][2], xf[t][ks], xf[t + 1][ks], acc[t][nt], acc[t + 1][nt]);
+    }
+    // v = acc*s + b; PReLU(v) = v + (slope - 1)*min(v, 0); channels 16 nt + 4 q + i of pixel l15
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 es = *(const f32x4*)&Pc[16 * nt + 4 * q];
+      const f32x4 eb = *(const f32x4*)&Pc[K::KCH + 16 * nt + 4 * q];
+      const f32x4 em = *(const f32x4*)&Pc[2 * K::KCH + 16 * nt + 4 * q] - f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int t = 0; t < K::NOWN; ++t) {
+        f32x4 v = acc[t][nt] * es + eb;
+        f32x4 neg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) neg[i] = __builtin_fminf(v[i], 0.f);
+        v = neg * em + v;
+        *(f32x4*)&El[eoff[t] + 16 * nt] = v;
+      }
+    }
+  };
+
+  // D(s, c): 3x3 depthwise + BN + PReLU of chunk c's rows, E-image -> D-tile (three bf16 planes).
+  // lane = (channel pair c2, column strip): the window slides down the rows with 3 LDS reads per output.
+  auto depthwise = [&](int s, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const float* Pc = Pl + (s & 1) * K::PL;
+    const int c2 = tid & 15, strip = tid >> 4;
+    f32x2 tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap[t] = *(const f32x2*)&Pc[(3 + t) * K::KCH + 2 * c2];
+    const f32x2 dsc = *(const f32x2*)&Pc[12 * K::KCH + 2 * c2];
+    const f32x2 dbi = *(const f32x2*)&Pc[13 * K::KCH + 2 * c2];
+    const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2] - f32x2{1.f, 1.f};
+#pragma unroll
+    for (int ps = 0; ps < K::NPASS; ++ps) {
+      const int col = strip + 16 * ps;
+      if (col < HW) {
+        // E pixel (vr, col + dx - 1) is slot vr*ROWP + col + dx; output row r of the band reads vr = r, r + 1, r + 2
+        const float* base = &El[(K::crow0(c) * K::ROWP + col) * K::LDE + 2 * c2];
+        unsigned* dst = (unsigned*)Dl + (col * 32 + 2 * c2) / 2;
+        f32x2 w0[3], w1[3], w2[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          w0[dx] = *(const f32x2*)(base + dx * K::LDE);
+          w1[dx] = *(const f32x2*)(base + (K::ROWP + dx) * K::LDE);
+        }
+#pragma unroll
+        for (int r = 0; r < K::crows(c); ++r) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) w2[dx] = *(const f32x2*)(base + ((r + 2) * K::ROWP + dx) * K::LDE);
+          f32x2 sacc = w0[0] * tap[0];
+          sacc += w0[1] * tap[1];
+          sacc += w0[2] * tap[2];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+          f32x2 v = sacc * dsc + dbi;
+          const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
+          v = neg * dsl + v;
+          unsigned h, m, l;
+          fp_split_pair(v[0], v[1], h, m, l);
+          dst[(r * HW * 32) / 2] = h;
+          dst[(K::DPL + r * HW * 32) / 2] = m;
+          dst[(2 * K::DPL + r * HW * 32) / 2] = l;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            w0[dx] = w1[dx];
+            w1[dx] = w2[dx];
+          }
+        }
+      }
+    }
+  };
+
+  // P(s, c): W_p^T (registers) x D^T -> pacc; two accumulators per step (two channel tiles, or two pixel tiles where a
+  // wave owns one channel tile); the D fragments of the next step are requested before this step's MFMAs
+  auto project = [&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    constexpr int TS = K::NCT == 2 ? 1 : 2;                 // pixel tiles per step
+    constexpr int NSTEP = (K::mtc(c) + TS - 1) / TS;
+    fp_frag3 df[2][TS];
+    auto ldd = [&](int st, fp_frag3* d) {
+#pragma unroll
+      for (int i = 0; i < TS; ++i) {
+        const int t = st * TS + i < K::mtc(c) ? st * TS + i : K::mtc(c) - 1;
+        const unsigned short* src = Dl + ((16 * t + l15) * 32 + 8 * q);
+        d[i].h = *(const u32x4*)src;
+        d[i].m = *(const u32x4*)(src + K::DPL);
+        d[i].l = *(const u32x4*)(src + 2 * K::DPL);
+      }
+    };
+    ldd(0, df[0]);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) ldd(st + 1, df[(st + 1) & 1]);
+      const fp_frag3* d = df[st & 1];
+      if (K::NCT == 2) {
+        fp_mfma_x6_2a(pbw[0], pbw[K::NCT - 1], d[0].h, d[0].m, d[0].l, pacc[K::tbase(c) + st][0], pacc[K::tbase(c) + st][K::NCT - 1]);
+      } else if (st * TS + 1 < K::mtc(c)) {
+        fp_mfma_x6_2(pbw[0], d[0], pbw[0], d[TS - 1], pacc[K::tbase(c) + st * TS][0], pacc[K::tbase(c) + st * TS + TS - 1][0]);
+      } else {
+        pacc[K::tbase(c) + st * TS][0] = fp_mfma_x6(pbw[0].h, pbw[0].m, pbw[0].l, d[0].h, d[0].m, d[0].l, pacc[K::tbase(c) + st * TS][0]);
+      }
+    }
+  };
+
+  // workgroup barrier that waits for this wave's LDS traffic only: an LDS-DMA (vmcnt) may stay in flight across it
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  if (p.stagger > 0 && (__builtin_amdgcn_s_getreg(0x1804) & 1))   // HW_ID.WAVE_ID: odd wave slot = second workgroup of the CU
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  __syncthreads();   // E-image zeroed, round 0 staged (the barrier drains the LDS-DMA)
+
+  for (int s = 0; s < R; ++s) {
+    X6_STAMP(0);
+    expand(s);
+    X6_STAMP(1);
+    __syncthreads();                       // E-image complete; every wave is done with this round's expand weights
+    X6_STAMP(2);
+    load_pbw(s);                           // first: vmcnt is in order, P waits for these and not for the DMA behind them
+    if (s + 1 < R) stage(s + 1);
+    depthwise(s, std::integral_constant<int, 0>());
+    X6_STAMP(3);
+    lds_barrier();                         // D-tile complete
+    X6_STAMP(4);
+    project(std::integral_constant<int, 0>());
+    X6_STAMP(5);
+    if (K::NCHUNK > 1) {
+      lds_barrier();                       // chunk 0's D-tile consumed
+      depthwise(s, std::integral_constant<int, K::NCHUNK - 1>());
+      lds_barrier();
+      project(std::integral_constant<int, K::NCHUNK - 1>());
+    }
+    if (s + 1 < R) __syncthreads();        // next round's weights and parameters landed (the DMA had D + P to do so)
+  }
+  {
+    [[maybe_unused]] const int s = R;
+    X6_STAMP(0);
+  }
+
+  // ---- epilogue: y = acc*s + b (+ x), lane = pixel l15 of the tile, channels 16 ct + 4 q .. + 3 ----
+#pragma unroll
+  for (int c = 0; c < K::NCHUNK; ++c) {
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j) {
+      const int ch = 16 * (wave * K::NCT + j) + 4 * q;
+      const f32x4 ps = *(const f32x4*)(p.paff + ch);
+      const f32x4 pb = *(const f32x4*)(p.paff + C + ch);
+      f32x4 rv[K::mtc(0)];
+#pragma unroll
+      for (int t = 0; t < K::mtc(c); ++t) {
+        const int o = min(16 * t + l15, K::crows(c) * HW - 1);
+        const int off = ((r0 + K::crow0(c)) * HW + o) * C + ch;
+        rv[t] = p.has_res ? *(const f32x4*)(xin + off) : z;
+      }
+#pragma unroll
+      for (int t = 0; t < K::mtc(c); ++t) {
+        const int o = 16 * t + l15;
+        const int off = ((r0 + K::crow0(c)) * HW + o) * C + ch;
+        const f32x4 v = pacc[K::tbase(c) + t][j] * ps + pb + rv[t];
+        if (o < K::crows(c) * HW) *(f32x4*)(yout + off) = v;
+      }
+    }
+  }
+}
+
+template <int C, int HW>
+int launch_x6(const DwbX6Args& a, hipStream_t s) {
+  using K = X6Cfg<C, HW>;
+  const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6_kernel<C, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            K::LDS_BYTES);
+  if (ae != hipSuccess) {
+    fp_set_hip_error(ae);
+    return FP_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((dwblock_x6_kernel<C, HW>), dim3(a.N * K::NBAND), dim3(256), K::LDS_BYTES, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+}  // namespace
+
+// Shapes the split kernel is instantiated for (include/facepath.h, DWBLOCK with FP_OPF_SPLIT3).
+bool fp_dwblock_x6_supported(const fp_op& op) {
+  if (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3)) return false;
+  if (op.stride != 1 || op.KH != 3 || op.KW != 3 || op.pad_t != 1 || op.pad_l != 1) return false;
+  if (op.OH != op.H || op.OW != op.W || op.H != op.W || op.Cout != op.Cin || op.out_cmul != 1) return false;
+  const bool shape = (op.Cin == 128 && op.H == 14) || (op.Cin == 64 && op.H == 28);
+  if (!shape || op.Cmid != 2 * op.Cin) return false;
+  const long ns = (long)op.H * op.W * op.Cin;
+  if (op.in_ld != op.Cin || op.out_ld != op.Cout || op.in_ns != ns || op.out_ns != ns || op.in_off % 4 || op.out_off % 4) return false;
+  if (op.w_off % 4 || op.scale_off % 4 || op.slope_off % 4) return false;
+  if (op.res_mode != FP_RES_NONE && op.res_mode != FP_RES_ADD_AFTER_ACT) return false;
+  if (op.res_mode == FP_RES_ADD_AFTER_ACT &&
+      (op.res_off != op.in_off || op.res_ns != op.in_ns || op.res_ld != op.in_ld || op.res_C != op.Cin)) return false;
+  if ((op.flags & ~FP_OPF_SPLIT3) || op.act2) return false;
+  if ((long)op.N * (op.H / 7) > 0x7fffffffL) return false;
+  return true;
+}
+
+// floats of the weight blob behind w_off / slope_off for a split DWBLOCK (capi.cpp bounds checks)
+long fp_dwblock_x6_we_floats(const fp_op& op) { return (long)op.Cmid * op.Cin * 3 / 2; }
+long fp_dwblock_x6_wp_floats(const fp_op& op) { return (long)op.Cmid * op.Cout * 3 / 2 + 2L * op.Cout; }
+
+int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  if (!fp_dwblock_x6_supported(op)) return FP_ERR_UNSUPPORTED;
+  DwbX6Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.we = (const unsigned short*)(weights + op.w_off);
+  a.par = weights + op.scale_off;
+  a.wp = (const unsigned short*)(weights + op.slope_off);
+  a.paff = weights + op.slope_off + (long)op.Cmid * op.Cout * 3 / 2;
+  a.N = op.N;
+  a.has_res = op.res_mode == FP_RES_ADD_AFTER_ACT;
+  static const int stagger = getenv("FP_X6_STAGGER") ? atoi(getenv("FP_X6_STAGGER")) : 0;
+  a.stagger = stagger;
+  if (op.Cin == 128) return launch_x6<128, 14>(a, s);
+  return launch_x6<64, 28>(a, s);
+}

@@ -87,6 +87,10 @@ class Depth_Wise(_NoCompute):
     # Whole block as ONE kernel (FP_OP_DWBLOCK, csrc/dwblock.hip) on the map sizes in BLOCK_SHAPES; None = block_policy
     # of the batch the plan will run on.  Tests pin it to a tuple.
     BLOCK_SHAPES = None
+    # Stride-1 blocks on the 14x14 and 28x28 maps as ONE kernel on the bf16 matrix cores with fp32-equivalent arithmetic
+    # (FP_OP_DWBLOCK + OPF_SPLIT3, csrc/dwblockx6.hip, csrc/split.h: exact three-way operand split, six products).
+    # False = every GEMM on the fp32 MFMA (the fmaf-chain kernels of rounds 1-3).
+    X6 = True
 
     @staticmethod
     def block_policy(n):
@@ -111,6 +115,13 @@ class Depth_Wise(_NoCompute):
             shapes = getattr(pb, "dwblock_shapes", None)
         if shapes is None:
             shapes = Depth_Wise.block_policy(pb.N)
+        if (Depth_Wise.FUSE and Depth_Wise.X6 and expanded is None and dw.k == 3 and dw.p == 1 and
+                (ex.in_c, x.H) in pb.DWBLOCK_X6_SHAPES and pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
+            y = pb.new_buf(x.H, x.W, pj.out_c)
+            pb.dwblock(x, npy(ex.conv.weight), _affine(ex.bn), npy(ex.prelu.weight),
+                       npy(dw.conv.weight), _affine(dw.bn), npy(dw.prelu.weight),
+                       npy(pj.conv.weight), _affine(pj.bn), y.view(), self.residual, split=True)
+            return y
         if (Depth_Wise.FUSE and expanded is None and x.H in shapes and dw.k == 3 and dw.p == 1 and
                 pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
             y = pb.new_buf(x.H, x.W, pj.out_c)
@@ -248,7 +259,7 @@ class MobileFaceNet(nn.Module):
         shapes = Depth_Wise.BLOCK_SHAPES if Depth_Wise.BLOCK_SHAPES is not None else \
             Depth_Wise.block_policy(N if n_run is None else n_run)
         shapes = tuple(shapes)
-        return self._plans.get((N, shapes, Depth_Wise.FUSE), lambda cache: self._build(N, cache, block_shapes=shapes))
+        return self._plans.get((N, shapes, Depth_Wise.FUSE, Depth_Wise.X6), lambda cache: self._build(N, cache, block_shapes=shapes))
 
     def forward(self, x):
         b = x.shape[0]

@@ -126,6 +126,20 @@ def pack_dw_weight(w, c_phys):
     return out.reshape(-1)
 
 
+def split3_bf16(w):
+    """The exact three-way bf16 split of fp32 values (csrc/split.h): w == h + m + l with h, m, l the sign-magnitude
+    truncations to 8 significant bits.  Returns uint16 [3, ...] (the top halves of the three fp32 bit patterns)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    mask = np.uint32(0xFFFF0000)
+    h = w.view(np.uint32) & mask
+    r = w - h.view(np.float32)
+    m = r.view(np.uint32) & mask
+    r2 = r - m.view(np.float32)
+    l = r2.view(np.uint32) & mask
+    assert np.array_equal(h.view(np.float32) + m.view(np.float32) + l.view(np.float32), w)
+    return np.stack([h >> 16, m >> 16, l >> 16]).astype(np.uint16)
+
+
 def pad_vec(v, n, fill=0.0):
     v = np.asarray(v, dtype=np.float32).reshape(-1)
     out = np.full((n,), fill, dtype=np.float32)
@@ -397,7 +411,10 @@ class PlanBuilder:
         return (stride == 1 and cin == cout and cmid == 2 * cin and x.H == x.W and (cin, x.H) in cls.DWBLOCK_SHAPES and
                 x.coff == 0 and x.C == cin and x.buf.ld == cin and x.buf.ns == x.H * x.W * cin and not x.buf.rowpad)
 
-    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual):
+    # shapes csrc/dwblockx6.hip (bf16x6 split MFMA, OPF_SPLIT3) is instantiated for
+    DWBLOCK_X6_SHAPES = ((128, 14), (64, 28))
+
+    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual, split=False):
         """A whole Depth_Wise block (mobile_facenet.py:67-88) as ONE op (FP_OP_DWBLOCK, csrc/dwblock.hip): 1x1 expand
         + BN + PReLU -> dw3x3 (stride 1) + BN + PReLU -> 1x1 project + BN [+ x]; the expanded tensor stays in LDS.
         *_aff = (scale, bias) of the eval-mode BatchNorm."""
@@ -411,12 +428,24 @@ class PlanBuilder:
         op.stride = 1
         op.pad_t = op.pad_l = 1
         op.act = L.ACT_PRELU
-        op.w_off = self.add_weight(pack_conv_weight(e_w, cin, cmid))
+        if split:
+            # three bf16 planes per matrix, in the fragment order of dwblock_x6_kernel (include/facepath.h, DWBLOCK)
+            assert (cin, x.H) in self.DWBLOCK_X6_SHAPES
+            op.flags |= L.OPF_SPLIT3
+            R = cmid // 32
+            e3 = split3_bf16(np.asarray(e_w, np.float32).reshape(cmid, cin))            # [3][g][k]
+            e3 = e3.reshape(3, R, 32, cin // 32, 32).transpose(1, 0, 3, 2, 4)            # [R][3][ks][g'][k']
+            p3 = split3_bf16(np.asarray(pw_w, np.float32).reshape(cout, cmid))           # [3][co][g]
+            p3 = p3.reshape(3, cout, R, 32).transpose(2, 0, 1, 3)                        # [R][3][co][g']
+            op.w_off = self.add_weight(np.ascontiguousarray(e3).reshape(-1).view(np.float32))
+            wp = np.ascontiguousarray(p3).reshape(-1).view(np.float32)
+        else:
+            op.w_off = self.add_weight(pack_conv_weight(e_w, cin, cmid))
+            wp = pack_conv_weight(pw_w, cmid, cout)
         rows = [pad_vec(e_aff[0], cmid), pad_vec(e_aff[1], cmid), pad_vec(e_slope, cmid), pack_dw_weight(dw_w, cmid),
                 pad_vec(dw_aff[0], cmid), pad_vec(dw_aff[1], cmid), pad_vec(dw_slope, cmid)]
         op.scale_off = self.add_weight(np.concatenate(rows))
-        op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(pw_w, cmid, cout), pad_vec(pw_aff[0], cout),
-                                                       pad_vec(pw_aff[1], cout)]))
+        op.slope_off = self.add_weight(np.concatenate([wp, pad_vec(pw_aff[0], cout), pad_vec(pw_aff[1], cout)]))
         if residual:
             op.res_mode = L.RES_ADD_AFTER_ACT
             op.res_ld, op.res_ns, op.res_off = op.in_ld, op.in_ns, op.in_off
@@ -597,7 +626,7 @@ class PlanCache:
     def device_weights(self, host, device):
         import torch
         for h, d in self._weights:
-            if d.device == device and h.shape == host.shape and np.array_equal(h, host):
+            if d.device == device and h.shape == host.shape and np.array_equal(h.view(np.uint32), host.view(np.uint32)):
                 return d
         d = torch.from_numpy(host).to(device)
         self._weights.append((host, d))

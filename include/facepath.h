@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 4
+#define FP_ABI_VERSION 5
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -147,6 +147,15 @@ typedef struct fp_op {
  *                unchanged.  The *_U8 ops (Cin = 3) always do.  Only valid with Cin = 4.
  */
 #define FP_OPF_IN_C3 4
+/*
+ * FP_OPF_SPLIT3 (ABI 5) : the op's 1x1-conv weight matrices are packed as THREE bf16 planes (the exact three-way split
+ *                of every fp32 weight, w == h + m + l, planes = the top 16 bits of h, m, l) for the "bf16x6" kernels:
+ *                fp32 operands on v_mfma_f32_16x16x32_bf16, six products per operand pair, fp32 accumulation, result as
+ *                accurate as the fp32 fmaf chain (csrc/split.h; gfx950 has no TF32 and its fp32 MFMA runs at the
+ *                vector rate).  Accepted: FP_OP_DWBLOCK with (Cin, H = W) in {(128, 14), (64, 28)}; layouts under
+ *                "DWBLOCK".  The semantics of the op (mobile_facenet.py:67-88) do not change.
+ */
+#define FP_OPF_SPLIT3 8
 
 /*
  * Weight blob layouts (packed by the host side, see
@@ -188,13 +197,17 @@ typedef struct fp_op {
  *            scale_off -> [15][Cmid]: rows 0..2 expand BN scale / BN bias / PReLU slope, rows 3..11 the depthwise taps
  *                         (ky*3 + kx), rows 12..14 depthwise BN scale / BN bias / PReLU slope
  *            slope_off -> project weights packed as CONV (K = Cmid, Npad = Cout), then [Cout] BN scale, [Cout] BN bias
+ *            With FP_OPF_SPLIT3 (bf16 elements, 2 per float of the blob; R = Cmid / 32 rounds of 32 expanded channels):
+ *            w_off     -> [R][3 planes][Cin / 32][32 g][32 k]: plane p of expand weight (g = 32 r + g', k = 32 ks + k')
+ *            slope_off -> [R][3 planes][Cout][32 g]: plane p of project weight (co, g = 32 r + g'), then (fp32) [Cout]
+ *                         BN scale, [Cout] BN bias;  scale_off as above.
  *   BLAZEPAIR : in = x (row-padded, FP_OPF_IN_ROWPAD, 24 channels, W = 128 or 64, H a multiple of 8 with H / band rows
  *            >= 2), out = y2 (dense or FP_OPF_OUT_ROWPAD); act = FP_ACT_RELU, res_mode = FP_RES_ADD_BEFORE_ACT (each
  *            block's shortcut is its own input).  The two blocks' parameters back to back, each as for BLAZEBLOCK:
  *            w_off -> [2][9][24] taps, scale_off -> [2][24] depthwise bias, slope_off -> [2] packed 1x1 (K = 24,
  *            Npad = 32: 768 floats each), bias_off -> [2][24] 1x1 bias.
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -495,11 +495,13 @@ def test_mobilefacenet_persistent_kernels_large_batch(dev, cin, cout, groups, st
     x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
     pb = PlanBuilder(n)
     inp = pb.new_buf(hw, hw, cin)
-    Depth_Wise.BLOCK_SHAPES = ()       # the two-launch form (what stride-2 blocks, 28x28 blocks and most batches run)
+    Depth_Wise.BLOCK_SHAPES = ()       # the two-launch fp32-MFMA form (stride-2 blocks; every block with Depth_Wise.X6 off)
+    Depth_Wise.X6 = False
     try:
         y = blk.emit(pb, inp.view())
     finally:
         Depth_Wise.BLOCK_SHAPES = None
+        Depth_Wise.X6 = True
     plan = CompiledPlan(pb, dev)
     names = [plan.kernel_name(i) for i in range(plan.n_ops)]
     # 28 x 28 / 56 x 56 shapes: the wave-private kernel (projection weights resident in LDS); 14 x 14: the workgroup one
@@ -541,10 +543,12 @@ def test_dwblock_whole_depth_wise_vs_oracle(dev, cin, hw, residual, n):
     pb = PlanBuilder(n)
     inp = pb.new_buf(hw, hw, cin)
     Depth_Wise.BLOCK_SHAPES = (hw,)
+    Depth_Wise.X6 = False
     try:
         y = blk.emit(pb, inp.view())
     finally:
         Depth_Wise.BLOCK_SHAPES = None
+        Depth_Wise.X6 = True
     plan = CompiledPlan(pb, dev)
     assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_kernel"), [plan.kernel_name(i) for i in range(plan.n_ops)]
     t = plan.buf_tensor(inp, n)
@@ -562,32 +566,90 @@ def test_dwblock_whole_depth_wise_vs_oracle(dev, cin, hw, residual, n):
     np.testing.assert_array_equal(t.permute(0, 3, 1, 2).cpu().numpy(), x)   # the input is only read
 
 
+@pytest.mark.parametrize("cin,hw,residual,n", [
+    (128, 14, True, 70),    # two 7-row bands per image (8 expand rows each)
+    (128, 14, False, 3),    # no shortcut, fewer tiles than CUs
+    (64, 28, True, 37),     # four bands, interior ones with both halo rows; D / P in two row chunks
+    (64, 28, False, 2),
+    (128, 14, True, 530),   # bench-like batch
+    (64, 28, True, 530),
+])
+def test_dwblock_x6_split_mfma_vs_oracle(dev, cin, hw, residual, n):
+    """FP_OP_DWBLOCK + FP_OPF_SPLIT3 (csrc/dwblockx6.hip): the whole Depth_Wise block on the bf16 matrix cores, fp32
+    operands split exactly into three bf16 pieces, six products, fp32 accumulation (csrc/split.h) -- against
+    mobilefacenet_ref._depth_wise (torch fp32 on the CPU; mobile_facenet.py:77-88) to the SAME bounds as the fp32-MFMA
+    kernel's test above: 1e-5 of the output scale, and element by element 2e-5 absolute + 1e-5 relative."""
+    rng = np.random.default_rng(3000 + hw + n)
+    blk = Depth_Wise(cin, cin, residual=residual, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=2 * cin)
+    sd = synth_state_dict(blk.state_dict(), 1200 + cin + hw)
+    blk.load_state_dict(sd)
+    x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, cin)
+    assert Depth_Wise.X6
+    y = blk.emit(pb, inp.view())
+    plan = CompiledPlan(pb, dev)
+    assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_x6_kernel"), [plan.kernel_name(i) for i in range(plan.n_ops)]
+    t = plan.buf_tensor(inp, n)
+    t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(y, n)
+    out_t.fill_(float("nan"))                   # every output element must be written
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.permute(0, 3, 1, 2).cpu().numpy()
+    ref = mobilefacenet_ref._depth_wise({k: torch.as_tensor(v) for k, v in sd.items()}, "", torch.from_numpy(x),
+                                        1, residual).numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert rel_err(got, ref) < 1e-5
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(t.permute(0, 3, 1, 2).cpu().numpy(), x)   # the input is only read
+    # and against fp64: not less accurate than the fp32 oracle itself
+    sd64 = {k: torch.as_tensor(v).double() for k, v in sd.items()}
+    ref64 = mobilefacenet_ref._depth_wise(sd64, "", torch.from_numpy(x).double(), 1, residual).numpy()
+    assert np.abs(got - ref64).max() <= 2.0 * np.abs(ref - ref64).max() + 1e-6
+
+
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
-    """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through a plan whose twelve
-    stride-1 Depth_Wise blocks are FP_OP_DWBLOCK (batch capacity 64, run on the golden's 4 images), and the same
-    images through the two-launch plan: both within the north_star's 1e-4 of the reference, 2e-6 of each other."""
+    """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through three plans (batch
+    capacity 64, run on the golden's 4 images): (a) the default -- the ten stride-1 blocks on 28x28 / 14x14 as the
+    bf16x6 split-MFMA kernel (FP_OPF_SPLIT3), (b) Depth_Wise.X6 off and all twelve stride-1 blocks as the fp32-MFMA
+    FP_OP_DWBLOCK, (c) X6 off, two-launch form.  Each within the north_star's 1e-4 of the reference (measured ~4e-7),
+    2e-6 of each other."""
     g = golden("mobilefacenet_forward")
     net = MobileFaceNet(512)
     net.load_state_dict(synth_state_dict(net.state_dict(), int(g["seed"])))
     net = net.to(dev)
     x = torch.from_numpy(g["x"]).to(dev)
     n = x.shape[0]
-    Depth_Wise.BLOCK_SHAPES = (28, 14, 7)
+
+    def run(plan):
+        plan.input[:n, ..., :3].copy_(x.permute(0, 2, 3, 1))
+        plan.input[:n, ..., 3:].zero_()
+        plan.run(n)
+        torch.cuda.synchronize()
+        return plan.out[:n].cpu().numpy().copy()
+
+    plan = net.plan_for(64)
+    ops = [plan.ops[i] for i in range(plan.n_ops)]
+    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 10
+    e_x6 = run(plan)
+    Depth_Wise.X6 = False
     try:
+        Depth_Wise.BLOCK_SHAPES = (28, 14, 7)
         plan = net.plan_for(64)
+        ops = [plan.ops[i] for i in range(plan.n_ops)]
+        assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK) == 12 and not any(o.flags & L.OPF_SPLIT3 for o in ops)
+        e_blk = run(plan)
+        Depth_Wise.BLOCK_SHAPES = ()
+        plan = net.plan_for(n)
+        assert L.OP_DWBLOCK not in [plan.ops[i].kind for i in range(plan.n_ops)]
+        e_two = run(plan)
     finally:
         Depth_Wise.BLOCK_SHAPES = None
-    kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
-    assert kinds.count(L.OP_DWBLOCK) == 12
-    plan.input[:n, ..., :3].copy_(x.permute(0, 2, 3, 1))
-    plan.input[:n, ..., 3:].zero_()
-    plan.run(n)
-    torch.cuda.synchronize()
-    e = plan.out[:n].cpu().numpy().copy()
-    assert np.abs(e - g["emb"]).max() < 1e-4
-    small = net(torch.from_numpy(g["x"])).cpu().numpy()
-    assert L.OP_DWBLOCK not in [net.plan_for(n).ops[i].kind for i in range(net.plan_for(n).n_ops)]
-    assert np.abs(e - small).max() < 2e-6
+        Depth_Wise.X6 = True
+    for e in (e_x6, e_blk, e_two):
+        assert np.abs(e - g["emb"]).max() < 1e-4
+    assert np.abs(e_blk - e_two).max() < 2e-6 and np.abs(e_x6 - e_two).max() < 2e-6
 
 
 @pytest.mark.parametrize("ks,cout,hw,n,act", [(5, 24, 256, 8, "relu"), (3, 64, 112, 48, "prelu"), (3, 24, 90, 70, "none")])
