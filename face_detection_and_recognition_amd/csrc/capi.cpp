@@ -285,7 +285,11 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "blazepair_kernel<%d>", op->W);
       return buf;
     case FP_OP_DWBLOCK:
-      if (op->flags & FP_OPF_SPLIT3) { snprintf(buf, sizeof(buf), "dwblock_x6_kernel<%d, %d>", op->Cin, op->H); return buf; }
+      if (op->flags & FP_OPF_SPLIT3) {
+        if (op->Cin == 128 && op->H == 7) snprintf(buf, sizeof(buf), "dwblock_x6q_kernel<%d>", op->H);
+        else snprintf(buf, sizeof(buf), "dwblock_x6_kernel<%d, %d>", op->Cin, op->H);
+        return buf;
+      }
       snprintf(buf, sizeof(buf), "dwblock_kernel<%d, %d, %d, %d>", op->Cin, op->H, op->H == 28 ? 7 : op->H, op->H == 7 ? 3 : 1);
       return buf;
     case FP_OP_STEM_U8:

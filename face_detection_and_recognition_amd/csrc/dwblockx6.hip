@@ -380,6 +380,269 @@ int launch_x6(const DwbX6Args& a, hipStream_t s) {
   return FP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 7 x 7 output tiles for the 128-channel blocks (14x14 maps: four tiles per image, 7x7 maps: one).  Same rounds and the
+// same arithmetic as the band kernel above; the smaller tile is about occupancy and granularity:
+//   * 51 KiB of LDS and <= 168 VGPRs: THREE workgroups per CU (the band form: two, 250 VGPRs), i.e. three waves per
+//     SIMD whose MFMA / VALU / waiting phases fill each other's gaps (the stamps of the band form showed each phase
+//     latency-bound on its own: E 2400, D 3000 -> 5300 beside the partner, P 1850 cycles per round);
+//   * 2112 tiles on 768 slots at 528 crops instead of 1056 on 512 (three rounds of workgroups for 2.06 rounds of work);
+//   * the halo costs nothing at 14x14: the 8 x 8 expand pixels of a tile are exactly four 16-pixel MFMA tiles (one per
+//     wave) where the band form has seven for four waves; the project GEMM pays 64 rows for 49 pixels.
+//   E-image: explicit 9 x 9 slot grid (tile + one pixel around), border slots outside the image stay zero.
+template <int HW>
+struct X6QCfg {
+  static_assert(HW == 14 || HW == 7, "");
+  static constexpr int C = 128, G = 256, KCH = 32, R = G / KCH, KS = C / 32;
+  static constexpr int TPR = HW / 7, TPI = TPR * TPR;   // tiles per row / per image
+  static constexpr int NC = HW == 14 ? 8 : 7;           // computed expand rows = columns of a tile
+  static constexpr int EPX = NC * NC;                   // 64 / 49 expand pixels: four 16-pixel tiles, one per wave
+  static constexpr int NSLOT = 81, LDE = 36, EB = (NSLOT + 1) * LDE;
+  static constexpr int MTP = 4;                         // 49 output pixels in four 16-pixel tiles
+  static constexpr int DPL = MTP * 16 * 32;
+  static constexpr int WL = 3 * KS * 32 * 32, PL = 15 * KCH;
+  static constexpr int LDS_BYTES = EB * 4 + 3 * DPL * 2 + WL * 2 + 2 * PL * 4;
+  static_assert(LDS_BYTES * 3 <= 160 * 1024, "three workgroups per CU");
+};
+
+template <int HW>
+__global__ __launch_bounds__(256, 3) void dwblock_x6q_kernel(DwbX6Args p) {
+  using K = X6QCfg<HW>;
+  constexpr int C = K::C, G = K::G, R = K::R, KS = K::KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* El = (float*)smem_raw;
+  unsigned short* Dl = (unsigned short*)(smem_raw + K::EB * 4);
+  unsigned short* Wl = Dl + 3 * K::DPL;
+  float* Pl = (float*)(Wl + K::WL);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int img = tile / K::TPI, tq = tile % K::TPI;
+  const int r0 = (tq / K::TPR) * 7, c0 = (tq % K::TPR) * 7;
+  const int er0 = r0 > 0 ? r0 - 1 : 0, ec0 = c0 > 0 ? c0 - 1 : 0;     // first computed expand row / column
+  const int vr0 = r0 > 0 ? 0 : 1, vc0 = c0 > 0 ? 0 : 1;               // its place in the 9 x 9 grid
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const float* xin = p.in + (long)img * (HW * HW * C);
+  float* yout = p.out + (long)img * (HW * HW * C);
+
+  auto stage = [&](int s) {
+    const unsigned char* src = (const unsigned char*)p.we + (long)s * (K::WL * 2) + lane * 16;
+#pragma unroll
+    for (int j = 0; j < K::WL * 2 / 4096; ++j) {
+      const int chunk = j * 4 + wave;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(src + chunk * 1024), (lds_ptr)((unsigned char*)Wl + chunk * 1024), 16, 0, 0);
+    }
+    if (wave < 2 && tid < 15 * 8) {
+      const float* ps = p.par + K::KCH * s + ((tid >> 3) * G + 4 * (tid & 7));
+      __builtin_amdgcn_global_load_lds((gbl_ptr)ps, (lds_ptr)(Pl + (s & 1) * K::PL + wave * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue ----
+  stage(0);
+  for (int i = tid; i < K::EB / 4; i += 256) *(f32x4*)&El[i * 4] = z;
+  // this wave's 16 expand pixels, split: lane = (pixel l15, k group q)
+  fp_frag3 xf[KS];
+  int eoff;
+  {
+    const int e = 16 * wave + l15;
+    const int ecl = min(e, K::EPX - 1);
+    const int er = ecl / K::NC, ec = ecl - er * K::NC;
+    const float* src = xin + ((er0 + er) * HW + ec0 + ec) * C + 8 * q;
+    f32x4 lo[KS], hi[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      lo[ks] = *(const f32x4*)(src + 32 * ks);
+      hi[ks] = *(const f32x4*)(src + 32 * ks + 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = fp_split8(lo[ks], hi[ks]);
+    const int slot = e < K::EPX ? (vr0 + er) * 9 + vc0 + ec : K::NSLOT;
+    eoff = slot * K::LDE + 4 * q;
+  }
+  f32x4 pacc[K::MTP][2];
+#pragma unroll
+  for (int t = 0; t < K::MTP; ++t) pacc[t][0] = pacc[t][1] = z;
+
+  fp_frag3 pbw[2];
+  auto load_pbw = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned short* src = p.wp + ((long)(s * 3 * C + 16 * (wave * 2 + j) + l15) * 32 + 8 * q);
+      pbw[j].h = *(const u32x4*)src;
+      pbw[j].m = *(const u32x4*)(src + C * 32);
+      pbw[j].l = *(const u32x4*)(src + 2 * C * 32);
+    }
+  };
+
+  // E(s): both 16-channel tiles of the round for this wave's pixel tile (two accumulators)
+  auto expand = [&](int s) {
+    const float* Pc = Pl + (s & 1) * K::PL;
+    f32x4 acc0 = z, acc1 = z;
+    // steps g = (ks, nt): the weight fragment of step g + 1 is requested before the six MFMAs of step g (a chain on one
+    // accumulator issues at the full rate: tools/lab/coexec_bf16_lab.hip)
+    fp_frag3 wf[2];
+    auto ldw = [&](int g, fp_frag3& w) {
+      const unsigned short* src = Wl + (((g >> 1) * 32 + 16 * (g & 1) + l15) * 32 + 8 * q);
+      w.h = *(const u32x4*)src;
+      w.m = *(const u32x4*)(src + KS * 1024);
+      w.l = *(const u32x4*)(src + 2 * KS * 1024);
+    };
+    ldw(0, wf[0]);
+#pragma unroll
+    for (int g = 0; g < 2 * KS; ++g) {
+      if (g + 1 < 2 * KS) ldw(g + 1, wf[(g + 1) & 1]);
+      const fp_frag3& w = wf[g & 1];
+      const fp_frag3& xx = xf[g >> 1];
+      if (g & 1) acc1 = fp_mfma_x6(w.h, w.m, w.l, xx.h, xx.m, xx.l, acc1);
+      else acc0 = fp_mfma_x6(w.h, w.m, w.l, xx.h, xx.m, xx.l, acc0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 es = *(const f32x4*)&Pc[16 * nt + 4 * q];
+      const f32x4 eb = *(const f32x4*)&Pc[K::KCH + 16 * nt + 4 * q];
+      const f32x4 em = *(const f32x4*)&Pc[2 * K::KCH + 16 * nt + 4 * q] - f32x4{1.f, 1.f, 1.f, 1.f};
+      f32x4 v = (nt ? acc1 : acc0) * es + eb;
+      f32x4 neg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) neg[i] = __builtin_fminf(v[i], 0.f);
+      v = neg * em + v;
+      *(f32x4*)&El[eoff + 16 * nt] = v;
+    }
+  };
+
+  // D(s): lane = (channel, column): ONE channel of one of the 7 columns, all 7 rows.  Rolling form: input row i feeds the
+  // bottom taps of output i - 2, the middle taps of i - 1 and the top taps of i -- three accumulators instead of a 3 x 3
+  // window (same order of additions per output).  Scalar fp32 math on purpose: beside the partner waves' MFMAs a
+  // v_pk_fma_f32 costs 22 cycles of issue against 2 x 8.7 for two v_fma_f32 (tools/lab/coexec_bf16_lab.hip), and one
+  // channel per lane needs a third of the registers of the channel-pair form (three workgroups per CU need <= 168).
+  // The three bf16 pieces are the upper halves of h, m, l: stored with ds_write_b16_d16_hi, no packing.
+  auto depthwise = [&](int s) {
+    const float* Pc = Pl + (s & 1) * K::PL;
+    const int ch = tid & 31, col = tid >> 5;
+    if (col < 7) {
+      float tap[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) tap[t] = Pc[(3 + t) * K::KCH + ch];
+      const float dsc = Pc[12 * K::KCH + ch], dbi = Pc[13 * K::KCH + ch], dsl = Pc[14 * K::KCH + ch] - 1.f;
+      // grid slot (vr, vc) = vr*9 + vc; output (row, col) reads vr = row .. row + 2, vc = col .. col + 2
+      const float* base = &El[col * K::LDE + ch];
+      unsigned short* dst = Dl + (col * 32 + ch);
+      float a0 = 0.f, a1 = 0.f, a2;   // a0: output i - 2 (complete after this row), a1: output i - 1, a2: output i
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float x0 = base[(i * 9) * K::LDE], x1 = base[(i * 9 + 1) * K::LDE], x2 = base[(i * 9 + 2) * K::LDE];
+        if (i >= 2) {
+          a0 = __builtin_fmaf(x0, tap[6], a0);
+          a0 = __builtin_fmaf(x1, tap[7], a0);
+          a0 = __builtin_fmaf(x2, tap[8], a0);
+          float v = __builtin_fmaf(a0, dsc, dbi);
+          v = __builtin_fmaf(__builtin_fminf(v, 0.f), dsl, v);
+          const unsigned hu = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+          const float r1 = v - __builtin_bit_cast(float, hu);
+          const unsigned mu = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+          const float r2 = r1 - __builtin_bit_cast(float, mu);
+          unsigned short* d = dst + (i - 2) * 7 * 32;   // upper halves: hipcc emits ds_write_b16_d16_hi
+          d[0] = (unsigned short)(hu >> 16);
+          d[K::DPL] = (unsigned short)(mu >> 16);
+          d[2 * K::DPL] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+        }
+        if (i >= 1 && i < 8) {
+          a1 = __builtin_fmaf(x0, tap[3], a1);
+          a1 = __builtin_fmaf(x1, tap[4], a1);
+          a1 = __builtin_fmaf(x2, tap[5], a1);
+        }
+        if (i < 7) {
+          a2 = x0 * tap[0];
+          a2 = __builtin_fmaf(x1, tap[1], a2);
+          a2 = __builtin_fmaf(x2, tap[2], a2);
+        }
+        a0 = a1;
+        a1 = a2;
+      }
+    }
+  };
+
+  auto project = [&]() {
+    fp_frag3 df[2];
+    auto ldd = [&](int t, fp_frag3& d) {
+      const unsigned short* src = Dl + ((16 * t + l15) * 32 + 8 * q);
+      d.h = *(const u32x4*)src;
+      d.m = *(const u32x4*)(src + K::DPL);
+      d.l = *(const u32x4*)(src + 2 * K::DPL);
+    };
+    ldd(0, df[0]);
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      if (t + 1 < K::MTP) ldd(t + 1, df[(t + 1) & 1]);
+      const fp_frag3& d = df[t & 1];
+      pacc[t][0] = fp_mfma_x6(pbw[0].h, pbw[0].m, pbw[0].l, d.h, d.m, d.l, pacc[t][0]);
+      pacc[t][1] = fp_mfma_x6(pbw[1].h, pbw[1].m, pbw[1].l, d.h, d.m, d.l, pacc[t][1]);
+    }
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  __syncthreads();
+  for (int s = 0; s < R; ++s) {
+    X6_STAMP(0);
+    expand(s);
+    X6_STAMP(1);
+    __syncthreads();
+    X6_STAMP(2);
+    load_pbw(s);
+    if (s + 1 < R) stage(s + 1);
+    depthwise(s);
+    X6_STAMP(3);
+    lds_barrier();
+    X6_STAMP(4);
+    project();
+    X6_STAMP(5);
+    if (s + 1 < R) __syncthreads();
+  }
+  {
+    [[maybe_unused]] const int s = R;
+    X6_STAMP(0);
+  }
+
+  // ---- epilogue: pixel o = 16 t + l15 of the tile (row o / 7, column o % 7), channels 16 (2 wave + j) + 4 q .. + 3 ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ch = 16 * (wave * 2 + j) + 4 * q;
+    const f32x4 ps = *(const f32x4*)(p.paff + ch);
+    const f32x4 pb = *(const f32x4*)(p.paff + C + ch);
+    f32x4 rv[K::MTP];
+    int off[K::MTP];
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      const int o = min(16 * t + l15, 48);
+      const int orow = o / 7, ocol = o - orow * 7;
+      off[t] = ((r0 + orow) * HW + c0 + ocol) * C + ch;
+      rv[t] = p.has_res ? *(const f32x4*)(xin + off[t]) : z;
+    }
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      const f32x4 v = pacc[t][j] * ps + pb + rv[t];
+      if (16 * t + l15 < 49) *(f32x4*)(yout + off[t]) = v;
+    }
+  }
+}
+
+template <int HW>
+int launch_x6q(const DwbX6Args& a, hipStream_t s) {
+  using K = X6QCfg<HW>;
+  const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6q_kernel<HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            K::LDS_BYTES);
+  if (ae != hipSuccess) {
+    fp_set_hip_error(ae);
+    return FP_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((dwblock_x6q_kernel<HW>), dim3(a.N * K::TPI), dim3(256), K::LDS_BYTES, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
 }  // namespace
 
 // Shapes the split kernel is instantiated for (include/facepath.h, DWBLOCK with FP_OPF_SPLIT3).
@@ -387,7 +650,7 @@ bool fp_dwblock_x6_supported(const fp_op& op) {
   if (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3)) return false;
   if (op.stride != 1 || op.KH != 3 || op.KW != 3 || op.pad_t != 1 || op.pad_l != 1) return false;
   if (op.OH != op.H || op.OW != op.W || op.H != op.W || op.Cout != op.Cin || op.out_cmul != 1) return false;
-  const bool shape = (op.Cin == 128 && op.H == 14) || (op.Cin == 64 && op.H == 28);
+  const bool shape = (op.Cin == 128 && (op.H == 14 || op.H == 7)) || (op.Cin == 64 && op.H == 28);
   if (!shape || op.Cmid != 2 * op.Cin) return false;
   const long ns = (long)op.H * op.W * op.Cin;
   if (op.in_ld != op.Cin || op.out_ld != op.Cout || op.in_ns != ns || op.out_ns != ns || op.in_off % 4 || op.out_off % 4) return false;
@@ -396,7 +659,7 @@ bool fp_dwblock_x6_supported(const fp_op& op) {
   if (op.res_mode == FP_RES_ADD_AFTER_ACT &&
       (op.res_off != op.in_off || op.res_ns != op.in_ns || op.res_ld != op.in_ld || op.res_C != op.Cin)) return false;
   if ((op.flags & ~FP_OPF_SPLIT3) || op.act2) return false;
-  if ((long)op.N * (op.H / 7) > 0x7fffffffL) return false;
+  if ((long)op.N * (op.H / 7) * (op.H / 7) > 0x7fffffffL) return false;
   return true;
 }
 
@@ -418,6 +681,9 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   a.has_res = op.res_mode == FP_RES_ADD_AFTER_ACT;
   static const int stagger = getenv("FP_X6_STAGGER") ? atoi(getenv("FP_X6_STAGGER")) : 0;
   a.stagger = stagger;
-  if (op.Cin == 128) return launch_x6<128, 14>(a, s);
+  // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
+  static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
+  if (op.Cin == 128 && op.H == 7) return launch_x6q<7>(a, s);
+  if (op.Cin == 128) return quarter14 ? launch_x6q<14>(a, s) : launch_x6<128, 14>(a, s);
   return launch_x6<64, 28>(a, s);
 }

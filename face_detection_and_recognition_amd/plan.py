@@ -412,7 +412,7 @@ class PlanBuilder:
                 x.coff == 0 and x.C == cin and x.buf.ld == cin and x.buf.ns == x.H * x.W * cin and not x.buf.rowpad)
 
     # shapes csrc/dwblockx6.hip (bf16x6 split MFMA, OPF_SPLIT3) is instantiated for
-    DWBLOCK_X6_SHAPES = ((128, 14), (64, 28))
+    DWBLOCK_X6_SHAPES = ((128, 14), (128, 7), (64, 28))
 
     def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual, split=False):
         """A whole Depth_Wise block (mobile_facenet.py:67-88) as ONE op (FP_OP_DWBLOCK, csrc/dwblock.hip): 1x1 expand

@@ -567,12 +567,14 @@ def test_dwblock_whole_depth_wise_vs_oracle(dev, cin, hw, residual, n):
 
 
 @pytest.mark.parametrize("cin,hw,residual,n", [
-    (128, 14, True, 70),    # two 7-row bands per image (8 expand rows each)
+    (128, 14, True, 70),    # four 7x7 tiles per image (8 x 8 expand pixels each)
     (128, 14, False, 3),    # no shortcut, fewer tiles than CUs
     (64, 28, True, 37),     # four bands, interior ones with both halo rows; D / P in two row chunks
     (64, 28, False, 2),
     (128, 14, True, 530),   # bench-like batch
     (64, 28, True, 530),
+    (128, 7, True, 65),     # 7x7 map: one tile per image, zero border all around
+    (128, 7, False, 530),
 ])
 def test_dwblock_x6_split_mfma_vs_oracle(dev, cin, hw, residual, n):
     """FP_OP_DWBLOCK + FP_OPF_SPLIT3 (csrc/dwblockx6.hip): the whole Depth_Wise block on the bf16 matrix cores, fp32
@@ -589,7 +591,7 @@ def test_dwblock_x6_split_mfma_vs_oracle(dev, cin, hw, residual, n):
     assert Depth_Wise.X6
     y = blk.emit(pb, inp.view())
     plan = CompiledPlan(pb, dev)
-    assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_x6_kernel"), [plan.kernel_name(i) for i in range(plan.n_ops)]
+    assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_x6"), [plan.kernel_name(i) for i in range(plan.n_ops)]
     t = plan.buf_tensor(inp, n)
     t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
     out_t = plan.buf_tensor(y, n)
@@ -611,7 +613,7 @@ def test_dwblock_x6_split_mfma_vs_oracle(dev, cin, hw, residual, n):
 
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
     """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through three plans (batch
-    capacity 64, run on the golden's 4 images): (a) the default -- the ten stride-1 blocks on 28x28 / 14x14 as the
+    capacity 64, run on the golden's 4 images): (a) the default -- all twelve stride-1 blocks as the
     bf16x6 split-MFMA kernel (FP_OPF_SPLIT3), (b) Depth_Wise.X6 off and all twelve stride-1 blocks as the fp32-MFMA
     FP_OP_DWBLOCK, (c) X6 off, two-launch form.  Each within the north_star's 1e-4 of the reference (measured ~4e-7),
     2e-6 of each other."""
@@ -631,7 +633,7 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
 
     plan = net.plan_for(64)
     ops = [plan.ops[i] for i in range(plan.n_ops)]
-    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 10
+    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 12
     e_x6 = run(plan)
     Depth_Wise.X6 = False
     try:

@@ -44,7 +44,7 @@ def time_plan(plan, reps=30):
 
 def main():
     dev = torch.device("cuda:0")
-    args = sys.argv[1:] or ["14:128", "14:256", "14:264", "14:384", "14:512", "14:528", "14:1024", "28:64", "28:128", "28:528", "28:1024"]
+    args = sys.argv[1:] or ["14:128", "14:256", "14:264", "14:384", "14:512", "14:528", "14:1024", "28:64", "28:128", "28:528", "28:1024", "7:528", "7:1024"]
     for a in args:
         hw, n = (int(v) for v in a.split(":"))
         cin = {28: 64, 14: 128, 7: 128}[hw]
