@@ -159,6 +159,8 @@ def reduce_time_and_count(elapsed, count, world, dist, dev, backend):
 # ---------------------------------------------------------------------------------------------------------------
 def run_pipeline(args):
     world, rank, dev, dist, backend = init_dist()
+    from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise
+    Depth_Wise.X6 = args.mfma == "bf16x6"
 
     # ---- workload (off the clock) ----
     batches = [W.make_frames(B_FRAMES, dev, seed=1234 + 97 * rank + b) for b in range(N_BATCHES)]
@@ -332,6 +334,28 @@ def run_pipeline(args):
                          "SURVEY 8(d)'s model (every reference conv reads its input and writes its output), which a fused "
                          "kernel beats by design; hbm_frac_from_traffic: PMC bytes of the committed profile / launch time"}
 
+    # ---- the same step with every GEMM on the fp32 MFMA (outside the timed region; rank 0, N = 1) ----
+    arith = None
+    if rank == 0:
+        arith = {"mobilefacenet_depth_wise": args.mfma,
+                 "note": "bf16x6: fp32 operands split EXACTLY into three bf16 pieces (w == h + m + l), six of the nine "
+                         "products on v_mfma_f32_16x16x32_bf16, fp32 accumulation; dropped terms <= 2^-23 of a product "
+                         "(one fp32 rounding); parity tests use the same bounds as for the fp32-MFMA kernels and check "
+                         "against fp64 that the error is not above the fp32 oracle's own; everything else fp32 throughout"}
+        if world == 1 and args.mfma == "bf16x6" and not args.no_fp32_leg:
+            Depth_Wise.X6 = False
+            try:
+                for k in range(3):
+                    step(k)
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                nq = sum(step(k) for k in range(20))
+                torch.cuda.synchronize()
+                dq = time.perf_counter() - tq
+                arith["fp32_mfma_only"] = {"ms_per_step": round(dq / 20 * 1e3, 3), "faces_per_s": round(nq / dq, 1), "steps": 20}
+            finally:
+                Depth_Wise.X6 = True
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         v, n_cpu, nfr, dt = cpu_baseline(det, emb, ref, batches[0][:args.cpu_frames].cpu(), pipe.tau)
@@ -356,7 +380,7 @@ def run_pipeline(args):
                                        f"{'RCCL' if backend == 'nccl' else backend + ' (CPU rehearsal)'} + cross-rank cosine match, "
                                        f"overlapped with the next step's detector (side stream, consumed one step late)"
                                        if world > 1 else "")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "arithmetic": arith,
         }
         print(json.dumps(line), flush=True)
     if multi:
@@ -435,6 +459,12 @@ def main():
     ap.add_argument("--workload", choices=["pipeline", "c5"], default="pipeline")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mfma", choices=["bf16x6", "fp32"], default="bf16x6",
+                    help="matrix arithmetic of the Mobile-FaceNet Depth_Wise blocks: bf16x6 = fp32 operands split exactly into "
+                         "three bf16 pieces, six products, fp32 accumulation (csrc/split.h; as accurate as the fp32 fmaf chain); "
+                         "fp32 = every GEMM on the fp32 MFMA (rounds 1-3)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short un-timed-region leg that re-measures the step "
+                                                               "with --mfma fp32 for the `arithmetic` object")
     ap.add_argument("--overlap", action="store_true",
                     help="software-pipeline the steps (FacePipeline.step_overlapped: batch k + 1's detector is enqueued "
                          "before the host reads batch k's face count).  Measured on one MI355X: 5.65-5.67 ms per step either "

@@ -643,6 +643,303 @@ int launch_x6q(const DwbX6Args& a, hipStream_t s) {
   return FP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of the band kernel: one 512-thread workgroup per CU, waves 0-3 are MATRIX waves (E and P: nothing
+// but MFMAs, fragment reads and the expand epilogue), waves 4-7 are VECTOR waves (the depthwise phase D, the operand
+// split, all staging).  The stamps of the symmetric form (tools/lab/x6_lab.hip) showed why: every phase of a round is
+// latency-bound on its own (E 2400, D 3000, P 1850 cycles for 3240 cycles of matrix-core work), and two symmetric
+// workgroups per CU only interleave by accident.  Here a SIMD always holds one wave of each kind, and the software
+// pipeline of dwblock.hip puts independent work into every step (ONE workgroup barrier per step):
+//     step k:   matrix waves  E(k + 1) -> E-image[(k + 1) & 1],   P(k - 1) <- D-tile[(k - 1) & 1]
+//               vector waves  stage round k + 2 (LDS-DMA),        D(k): E-image[k & 1] -> D-tile[k & 1]
+// An MFMA holds the SIMD's issue port for 8 of its ~18 cycles: the vector wave gets about two VALU slots per MFMA
+// (tools/lab/coexec_bf16_lab.hip), which is what D needs (~1.6 per MFMA of its SIMD).
+#ifdef FP_X6_STAMPS
+#define X6S_STAMP(k)                                                                                  \
+  do {                                                                                                \
+    if (p.stamps && blockIdx.x < 2 && (threadIdx.x & 63) == 0) {                                      \
+      unsigned long long tt_;                                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");                     \
+      p.stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 9 + s) * 4 + (k)] = tt_;                      \
+    }                                                                                                 \
+  } while (0)
+#else
+#define X6S_STAMP(k) do { } while (0)
+#endif
+
+template <int C, int HW>
+struct X6SCfg : X6Cfg<C, HW> {
+  using B = X6Cfg<C, HW>;
+  static_assert(B::NCHUNK == 1, "whole-band D / P");
+  static constexpr int LDS_BYTES = 2 * B::EB * 4 + 2 * 3 * B::DPL * 2 + 2 * B::WL * 2 + 3 * B::PL * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+};
+
+template <int C, int HW>
+__global__ __launch_bounds__(512, 1) void dwblock_x6s_kernel(DwbX6Args p) {
+  using K = X6SCfg<C, HW>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* El = (float*)smem_raw;                                            // [2][EB]
+  unsigned short* Dl = (unsigned short*)(smem_raw + 2 * K::EB * 4);        // [2][3][DPL]
+  unsigned short* Wl = Dl + 2 * 3 * K::DPL;                                // [2][WL]
+  float* Pl = (float*)(Wl + 2 * K::WL);                                    // [3][PL]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool matrix = wave < 4;
+  const int mw = wave & 3;                                                 // index inside the role
+  const int l15 = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int img = tile / K::NBAND;
+  const int r0 = (tile % K::NBAND) * K::RB;
+  const int elo = r0 > 0 ? r0 - 1 : 0;
+  const int ehi = r0 + K::RB < HW ? r0 + K::RB : HW - 1;
+  const int epx = (ehi - elo + 1) * HW;
+  const int vr0 = r0 > 0 ? 0 : 1;
+  constexpr int G = K::G, R = K::R, KS = K::KS;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const float* xin = p.in + (long)img * (HW * HW * C);
+  float* yout = p.out + (long)img * (HW * HW * C);
+
+  // staging by the four vector waves (mw = 0 .. 3): round s -> Wl[s & 1], Pl[s % 3]
+  auto stage = [&](int s) {
+    const unsigned char* src = (const unsigned char*)p.we + (long)s * (K::WL * 2) + lane * 16;
+    unsigned char* dst = (unsigned char*)(Wl + (s & 1) * K::WL);
+#pragma unroll
+    for (int j = 0; j < K::WL * 2 / 4096; ++j) {
+      const int chunk = j * 4 + mw;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(src + chunk * 1024), (lds_ptr)(dst + chunk * 1024), 16, 0, 0);
+    }
+    const int t = tid - 256;
+    if (mw < 2 && t < 15 * 8) {
+      const float* ps = p.par + K::KCH * s + ((t >> 3) * G + 4 * (t & 7));
+      __builtin_amdgcn_global_load_lds((gbl_ptr)ps, (lds_ptr)(Pl + (s % 3) * K::PL + mw * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue ----
+  if (!matrix) {
+    stage(0);
+    if (R > 1) stage(1);
+  }
+  for (int i = tid; i < 2 * K::EB / 4; i += 512) *(f32x4*)&El[i * 4] = z;
+  fp_frag3 xf[K::NOWN][KS];
+  int eoff[K::NOWN];
+  f32x4 pacc[K::MTP][K::NCT];
+  fp_frag3 pbw[K::NCT];
+  if (matrix) {
+#pragma unroll
+    for (int t = 0; t < K::NOWN; ++t) {
+      const int m = mw + 4 * t;
+      const int e = 16 * m + l15;
+      const int ec_ = min(e, epx - 1);
+      const float* src = xin + (elo * HW + ec_) * C + 8 * q;
+      f32x4 lo[KS], hi[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        lo[ks] = *(const f32x4*)(src + 32 * ks);
+        hi[ks] = *(const f32x4*)(src + 32 * ks + 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[t][ks] = fp_split8(lo[ks], hi[ks]);
+      const int er = ec_ / HW, ecol = ec_ - er * HW;
+      const int slot = e < epx ? (vr0 + er) * K::ROWP + ecol + 1 : K::NSLOT;
+      eoff[t] = slot * K::LDE + 4 * q;
+    }
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t)
+#pragma unroll
+      for (int j = 0; j < K::NCT; ++j) pacc[t][j] = z;
+  }
+
+  auto load_pbw = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j) {
+      const unsigned short* src = p.wp + ((long)(s * 3 * C + 16 * (mw * K::NCT + j) + l15) * 32 + 8 * q);
+      pbw[j].h = *(const u32x4*)src;
+      pbw[j].m = *(const u32x4*)(src + C * 32);
+      pbw[j].l = *(const u32x4*)(src + 2 * C * 32);
+    }
+  };
+
+  // E(s) (matrix waves): expand round s -> E-image[s & 1]
+  auto expand = [&](int s) {
+    const float* Pc = Pl + (s % 3) * K::PL;
+    const unsigned short* Wc = Wl + (s & 1) * K::WL;
+    float* Ec = El + (s & 1) * K::EB;
+    f32x4 acc[K::NOWN][2];
+#pragma unroll
+    for (int t = 0; t < K::NOWN; ++t) acc[t][0] = acc[t][1] = z;
+    fp_frag3 wf[2];
+    auto ldw = [&](int g, fp_frag3& w) {
+      const unsigned short* src = Wc + (((g >> 1) * 32 + 16 * (g & 1) + l15) * 32 + 8 * q);
+      w.h = *(const u32x4*)src;
+      w.m = *(const u32x4*)(src + KS * 1024);
+      w.l = *(const u32x4*)(src + 2 * KS * 1024);
+    };
+    ldw(0, wf[0]);
+#pragma unroll
+    for (int g = 0; g < 2 * KS; ++g) {
+      if (g + 1 < 2 * KS) ldw(g + 1, wf[(g + 1) & 1]);
+      const fp_frag3& w = wf[g & 1];
+#pragma unroll
+      for (int t = 0; t < K::NOWN; ++t)
+        acc[t][g & 1] = fp_mfma_x6(w.h, w.m, w.l, xf[t][g >> 1].h, xf[t][g >> 1].m, xf[t][g >> 1].l, acc[t][g & 1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 es = *(const f32x4*)&Pc[16 * nt + 4 * q];
+      const f32x4 eb = *(const f32x4*)&Pc[K::KCH + 16 * nt + 4 * q];
+      const f32x4 em = *(const f32x4*)&Pc[2 * K::KCH + 16 * nt + 4 * q] - f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int t = 0; t < K::NOWN; ++t) {
+        f32x4 v = acc[t][nt] * es + eb;
+        f32x4 neg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) neg[i] = __builtin_fminf(v[i], 0.f);
+        v = neg * em + v;
+        *(f32x4*)&Ec[eoff[t] + 16 * nt] = v;
+      }
+    }
+  };
+
+  // D(s) (vector waves): lane = (channel pair c2, column strip), all 7 rows
+  auto depthwise = [&](int s) {
+    const float* Pc = Pl + (s % 3) * K::PL;
+    const float* Ec = El + (s & 1) * K::EB;
+    unsigned short* Dc = Dl + (s & 1) * 3 * K::DPL;
+    const int vt = tid - 256;
+    const int c2 = vt & 15, strip = vt >> 4;
+    f32x2 tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap[t] = *(const f32x2*)&Pc[(3 + t) * K::KCH + 2 * c2];
+    const f32x2 dsc = *(const f32x2*)&Pc[12 * K::KCH + 2 * c2];
+    const f32x2 dbi = *(const f32x2*)&Pc[13 * K::KCH + 2 * c2];
+    const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2] - f32x2{1.f, 1.f};
+#pragma unroll
+    for (int ps = 0; ps < K::NPASS; ++ps) {
+      const int col = strip + 16 * ps;
+      if (col < HW) {
+        const float* base = &Ec[col * K::LDE + 2 * c2];
+        unsigned* dst = (unsigned*)Dc + (col * 32 + 2 * c2) / 2;
+        f32x2 w0[3], w1[3], w2[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          w0[dx] = *(const f32x2*)(base + dx * K::LDE);
+          w1[dx] = *(const f32x2*)(base + (K::ROWP + dx) * K::LDE);
+        }
+#pragma unroll
+        for (int r = 0; r < K::RB; ++r) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) w2[dx] = *(const f32x2*)(base + ((r + 2) * K::ROWP + dx) * K::LDE);
+          f32x2 sacc = w0[0] * tap[0];
+          sacc += w0[1] * tap[1];
+          sacc += w0[2] * tap[2];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+          f32x2 v = sacc * dsc + dbi;
+          const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
+          v = neg * dsl + v;
+          unsigned h, m, l;
+          fp_split_pair(v[0], v[1], h, m, l);
+          dst[(r * HW * 32) / 2] = h;
+          dst[(K::DPL + r * HW * 32) / 2] = m;
+          dst[(2 * K::DPL + r * HW * 32) / 2] = l;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            w0[dx] = w1[dx];
+            w1[dx] = w2[dx];
+          }
+        }
+      }
+    }
+  };
+
+  // P(s) (matrix waves): W_p^T (registers) x D^T -> pacc
+  auto project = [&](int s) {
+    const unsigned short* Dc = Dl + (s & 1) * 3 * K::DPL;
+    fp_frag3 df[2];
+    auto ldd = [&](int t, fp_frag3& d) {
+      const unsigned short* src = Dc + ((16 * t + l15) * 32 + 8 * q);
+      d.h = *(const u32x4*)src;
+      d.m = *(const u32x4*)(src + K::DPL);
+      d.l = *(const u32x4*)(src + 2 * K::DPL);
+    };
+    ldd(0, df[0]);
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      if (t + 1 < K::MTP) ldd(t + 1, df[(t + 1) & 1]);
+      const fp_frag3& d = df[t & 1];
+#pragma unroll
+      for (int j = 0; j < K::NCT; ++j) pacc[t][j] = fp_mfma_x6(pbw[j].h, pbw[j].m, pbw[j].l, d.h, d.m, d.l, pacc[t][j]);
+    }
+  };
+
+  __syncthreads();              // E-images zeroed, rounds 0 and 1 staged
+  if (matrix) {
+    expand(0);
+    load_pbw(0);
+  }
+  __syncthreads();
+  for (int k = 0; k < R; ++k) {
+    [[maybe_unused]] const int s = k;
+    X6S_STAMP(0);
+    if (matrix) {
+      if (k + 1 < R) expand(k + 1);
+      X6S_STAMP(1);
+      if (k > 0) {
+        project(k - 1);
+        load_pbw(k);            // consumed by P(k) in the next step
+      }
+    } else {
+      if (k + 2 < R) stage(k + 2);   // Wl[k & 1]: E(k) read it in the previous step; Pl[(k + 2) % 3]: last read by D(k - 1)
+      X6S_STAMP(1);
+      depthwise(k);
+    }
+    X6S_STAMP(2);
+    __syncthreads();
+    X6S_STAMP(3);
+  }
+  if (!matrix) return;
+  project(R - 1);
+
+  // ---- epilogue (matrix waves) ----
+#pragma unroll
+  for (int j = 0; j < K::NCT; ++j) {
+    const int ch = 16 * (mw * K::NCT + j) + 4 * q;
+    const f32x4 ps = *(const f32x4*)(p.paff + ch);
+    const f32x4 pb = *(const f32x4*)(p.paff + C + ch);
+    f32x4 rv[K::MTP];
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      const int o = min(16 * t + l15, K::RB * HW - 1);
+      rv[t] = p.has_res ? *(const f32x4*)(xin + ((r0 * HW + o) * C + ch)) : z;
+    }
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      const int o = 16 * t + l15;
+      const f32x4 v = pacc[t][j] * ps + pb + rv[t];
+      if (o < K::RB * HW) *(f32x4*)(yout + ((r0 * HW + o) * C + ch)) = v;
+    }
+  }
+}
+
+template <int C, int HW>
+int launch_x6s(const DwbX6Args& a, hipStream_t s) {
+  using K = X6SCfg<C, HW>;
+  const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6s_kernel<C, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            K::LDS_BYTES);
+  if (ae != hipSuccess) {
+    fp_set_hip_error(ae);
+    return FP_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((dwblock_x6s_kernel<C, HW>), dim3(a.N * K::NBAND), dim3(512), K::LDS_BYTES, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
 }  // namespace
 
 // Shapes the split kernel is instantiated for (include/facepath.h, DWBLOCK with FP_OPF_SPLIT3).
@@ -684,6 +981,9 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
   static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
   if (op.Cin == 128 && op.H == 7) return launch_x6q<7>(a, s);
-  if (op.Cin == 128) return quarter14 ? launch_x6q<14>(a, s) : launch_x6<128, 14>(a, s);
+  // lab knob: the wave-specialised form (matrix waves / vector waves; measured 141 against 126 us at 528 crops: its D phase
+  // runs 4500 cycles beside the matrix waves' MFMAs, tools/lab/x6_lab.hip)
+  static const int spec14 = getenv("FP_X6_SPEC14") ? atoi(getenv("FP_X6_SPEC14")) : 0;
+  if (op.Cin == 128) return quarter14 ? launch_x6q<14>(a, s) : spec14 ? launch_x6s<128, 14>(a, s) : launch_x6<128, 14>(a, s);
   return launch_x6<64, 28>(a, s);
 }

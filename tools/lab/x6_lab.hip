@@ -157,7 +157,71 @@ static void runq(int Nmax) {
   hipFree(x); hipFree(y); hipFree(w); hipFree(stamps);
 }
 
+// the wave-specialised band kernel (dwblock_x6s_kernel): per step [E (matrix) or staging (vector) | P or D | barrier]
+template <int C, int HW>
+static void runs(int Nmax) {
+  using K = X6SCfg<C, HW>;
+  constexpr int G = 2 * C;
+  hipFuncSetAttribute((const void*)dwblock_x6s_kernel<C, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+  printf("dwblock_x6s<%d,%d>: LDS %d B\n", C, HW, K::LDS_BYTES);
+  const long elems = (long)Nmax * HW * HW * C;
+  const long wfl = (long)C * G * 3 / 2 + 15L * G + (long)G * C * 3 / 2 + 2 * C;
+  float *x, *y, *w;
+  hipMalloc(&x, elems * 4); hipMalloc(&y, elems * 4); hipMalloc(&w, wfl * 4);
+  std::vector<float> hx(elems);
+  std::vector<unsigned> hw(wfl);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : hx) v = rnd();
+  for (auto& v : hw) { const float f = 0.05f * rnd(); unsigned u; memcpy(&u, &f, 4); v = (u & 0xffff0000u) | (u >> 16); }
+  hipMemcpy(x, hx.data(), elems * 4, hipMemcpyHostToDevice);
+  hipMemcpy(w, hw.data(), wfl * 4, hipMemcpyHostToDevice);
+  unsigned long long* stamps;
+  const size_t ns = 2 * 8 * 9 * 4;
+  hipMalloc(&stamps, ns * 8);
+  DwbX6Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = x; a.out = y;
+  a.we = (const unsigned short*)w;
+  a.par = w + (long)C * G * 3 / 2;
+  a.wp = (const unsigned short*)(a.par + 15L * G);
+  a.paff = a.par + 15L * G + (long)G * C * 3 / 2;
+  a.has_res = 1; a.stamps = nullptr;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int N : {64, 128, 256, 528, 1024}) {
+    if (N > Nmax) continue;
+    a.N = N;
+    for (int i = 0; i < 2; ++i) launch_x6s<C, HW>(a, 0);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) launch_x6s<C, HW>(a, 0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("  N=%5d tiles=%5d: %8.1f us per launch\n", N, N * K::NBAND, ms * 100);
+  }
+  a.N = 128;
+  a.stamps = stamps;
+  hipMemset(stamps, 0, ns * 8);
+  launch_x6s<C, HW>(a, 0);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(ns);
+  hipMemcpy(h.data(), stamps, ns * 8, hipMemcpyDeviceToHost);
+  printf("  cycles per step: matrix waves 0-3 [E | P | barrier], vector waves 4-7 [stage | D | barrier]\n");
+  for (int wv = 0; wv < 8; ++wv) {
+    printf("  w%d:", wv);
+    for (int c = 0; c < K::R; ++c) {
+      const unsigned long long* t = &h[(wv * 9 + c) * 4];
+      printf("  [%5lld %5lld %5lld]", (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]));
+    }
+    printf("\n");
+  }
+  hipFree(x); hipFree(y); hipFree(w); hipFree(stamps);
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && atoi(argv[1]) == 1) { runs<128, 14>(1024); return 0; }
   const int C = argc > 1 ? atoi(argv[1]) : 128;
   if (C == 14 || C == 7) { if (C == 14) runq<14>(1024); else runq<7>(1024); return 0; }
   if (C == 128) run<128, 14>(1024);
