@@ -286,7 +286,8 @@ const char* fp_op_kernel_name(const fp_op* op) {
       return buf;
     case FP_OP_DWBLOCK:
       if (op->flags & FP_OPF_SPLIT3) {
-        if (op->Cin == 128 && op->H == 7) snprintf(buf, sizeof(buf), "dwblock_x6q_kernel<%d>", op->H);
+        if (op->stride == 2) snprintf(buf, sizeof(buf), "dwblock_x6d_kernel<%d, %d, %d, %d>", op->Cin, op->Cmid, op->Cout, op->H);
+        else if (op->Cin == 128 && op->H == 7) snprintf(buf, sizeof(buf), "dwblock_x6q_kernel<%d>", op->H);
         else snprintf(buf, sizeof(buf), "dwblock_x6_kernel<%d, %d>", op->Cin, op->H);
         return buf;
       }

@@ -940,17 +940,281 @@ int launch_x6s(const DwbX6Args& a, hipStream_t s) {
   return FP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 Depth_Wise blocks (conv_34: 64 -> 128 on 28x28 -> 14x14, conv_45: 128 -> 128 on 14x14 -> 7x7;
+// mobile_facenet.py:118,123: expand to `groups` channels, depthwise 3x3 stride 2, project, no shortcut) in the band
+// form: a tile is 4 output rows = 9 input rows (2r - 1 .. 2r + 7), whose expand values fill the same 9-row E-image as
+// the stride-1 bands; the depthwise phase reads rows 2r .. 2r + 2 and columns 2c - 1 .. 2c + 1 of it.  Round 2 ran
+// these blocks as pws_kernel (expand, the G-channel tensor to HBM and back) + dwpw_kernel: 317 and 251 us at 528 crops.
+template <int CI, int G_, int CO, int HW>
+struct X6DCfg {
+  static_assert((CI == 64 && G_ == 256 && CO == 128 && HW == 28) || (CI == 128 && G_ == 512 && CO == 128 && HW == 14), "");
+  static constexpr int RBO = 4;                          // output rows of a tile
+  static constexpr int G = G_, KCH = 32, R = G / KCH, KS = CI / 32;
+  static constexpr int HO = HW / 2, WO = HW / 2;
+  static constexpr int NBAND = (HO + RBO - 1) / RBO;
+  static constexpr int ER = 2 * RBO + 1;                 // expand rows of a tile
+  static constexpr int EPX = ER * HW;
+  static constexpr int MTE = (EPX + 15) / 16;
+  static constexpr int NOWN = (MTE + 3) / 4;
+  static constexpr int ROWP = HW + 1;
+  static constexpr int NSLOT = ER * ROWP + 1;
+  static constexpr int LDE = 36;
+  static constexpr int EB = (NSLOT + 1) * LDE;
+  static constexpr int OPX = RBO * WO;                   // output pixels of a tile
+  static constexpr int MTP = (OPX + 15) / 16;
+  static constexpr int DPL = MTP * 16 * 32;
+  static constexpr int WL = 3 * KS * 32 * 32;
+  static constexpr int PL = 15 * KCH;
+  static constexpr int NCT = CO / 64;
+  static constexpr int NPART = WO <= 8 ? 2 : 1;          // depthwise strips: (row part, column)
+  static constexpr int RP = RBO / NPART;                 // output rows per strip
+  static constexpr int LDS_BYTES = EB * 4 + 3 * DPL * 2 + WL * 2 + 2 * PL * 4;
+  static_assert(LDS_BYTES <= 80 * 1024 && NPART * WO <= 16 && MTE <= 4 * NOWN && (WL * 2) % 4096 == 0, "");
+};
+
+template <int CI, int G_, int CO, int HW>
+__global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
+  using K = X6DCfg<CI, G_, CO, HW>;
+  constexpr int G = K::G, R = K::R, KS = K::KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* El = (float*)smem_raw;
+  unsigned short* Dl = (unsigned short*)(smem_raw + K::EB * 4);
+  unsigned short* Wl = Dl + 3 * K::DPL;
+  float* Pl = (float*)(Wl + K::WL);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int img = tile / K::NBAND;
+  const int ro0 = (tile % K::NBAND) * K::RBO;                          // first output row
+  const int nro = min(K::RBO, K::HO - ro0);                            // output rows of this band
+  const int first = 2 * ro0 - 1;                                       // input row of E-image row 0
+  const int elo = first > 0 ? first : 0;
+  const int ehi = min(2 * ro0 + 2 * nro - 1, HW - 1);
+  const int epx = (ehi - elo + 1) * HW;
+  const int vr0 = elo - first;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const float* xin = p.in + (long)img * (HW * HW * CI);
+  float* yout = p.out + (long)img * (K::HO * K::WO * CO);
+
+  auto stage = [&](int s) {
+    const unsigned char* src = (const unsigned char*)p.we + (long)s * (K::WL * 2) + lane * 16;
+#pragma unroll
+    for (int j = 0; j < K::WL * 2 / 4096; ++j) {
+      const int chunk = j * 4 + wave;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(src + chunk * 1024), (lds_ptr)((unsigned char*)Wl + chunk * 1024), 16, 0, 0);
+    }
+    if (wave < 2 && tid < 15 * 8) {
+      const float* ps = p.par + K::KCH * s + ((tid >> 3) * G + 4 * (tid & 7));
+      __builtin_amdgcn_global_load_lds((gbl_ptr)ps, (lds_ptr)(Pl + (s & 1) * K::PL + wave * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue ----
+  stage(0);
+  for (int i = tid; i < K::EB / 4; i += 256) *(f32x4*)&El[i * 4] = z;
+  fp_frag3 xf[K::NOWN][KS];
+  int eoff[K::NOWN];
+#pragma unroll
+  for (int t = 0; t < K::NOWN; ++t) {
+    const int e = 16 * (wave + 4 * t) + l15;
+    const int ec_ = min(e, epx - 1);
+    const float* src = xin + (elo * HW + ec_) * CI + 8 * q;
+    f32x4 lo[KS], hi[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      lo[ks] = *(const f32x4*)(src + 32 * ks);
+      hi[ks] = *(const f32x4*)(src + 32 * ks + 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[t][ks] = fp_split8(lo[ks], hi[ks]);
+    const int er = ec_ / HW, ecol = ec_ - er * HW;
+    const int slot = e < epx ? (vr0 + er) * K::ROWP + ecol + 1 : K::NSLOT;
+    eoff[t] = slot * K::LDE + 4 * q;
+  }
+  f32x4 pacc[K::MTP][K::NCT];
+#pragma unroll
+  for (int t = 0; t < K::MTP; ++t)
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j) pacc[t][j] = z;
+
+  fp_frag3 pbw[K::NCT];
+  auto load_pbw = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j) {
+      const unsigned short* src = p.wp + ((long)(s * 3 * CO + 16 * (wave * K::NCT + j) + l15) * 32 + 8 * q);
+      pbw[j].h = *(const u32x4*)src;
+      pbw[j].m = *(const u32x4*)(src + CO * 32);
+      pbw[j].l = *(const u32x4*)(src + 2 * CO * 32);
+    }
+  };
+
+  auto expand = [&](int s) {
+    const float* Pc = Pl + (s & 1) * K::PL;
+    f32x4 acc[K::NOWN][2];
+#pragma unroll
+    for (int t = 0; t < K::NOWN; ++t) acc[t][0] = acc[t][1] = z;
+    fp_frag3 wf[2];
+    auto ldw = [&](int g, fp_frag3& w) {
+      const unsigned short* src = Wl + (((g >> 1) * 32 + 16 * (g & 1) + l15) * 32 + 8 * q);
+      w.h = *(const u32x4*)src;
+      w.m = *(const u32x4*)(src + KS * 1024);
+      w.l = *(const u32x4*)(src + 2 * KS * 1024);
+    };
+    ldw(0, wf[0]);
+#pragma unroll
+    for (int g = 0; g < 2 * KS; ++g) {
+      if (g + 1 < 2 * KS) ldw(g + 1, wf[(g + 1) & 1]);
+      const fp_frag3& w = wf[g & 1];
+#pragma unroll
+      for (int t = 0; t < K::NOWN; ++t)
+        acc[t][g & 1] = fp_mfma_x6(w.h, w.m, w.l, xf[t][g >> 1].h, xf[t][g >> 1].m, xf[t][g >> 1].l, acc[t][g & 1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 es = *(const f32x4*)&Pc[16 * nt + 4 * q];
+      const f32x4 eb = *(const f32x4*)&Pc[K::KCH + 16 * nt + 4 * q];
+      const f32x4 em = *(const f32x4*)&Pc[2 * K::KCH + 16 * nt + 4 * q] - f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int t = 0; t < K::NOWN; ++t) {
+        f32x4 v = acc[t][nt] * es + eb;
+        f32x4 neg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) neg[i] = __builtin_fminf(v[i], 0.f);
+        v = neg * em + v;
+        *(f32x4*)&El[eoff[t] + 16 * nt] = v;
+      }
+    }
+  };
+
+  // D(s): lane = (channel pair c2, strip); strip = (row part, output column); output (r, c) reads E-image rows
+  // 2r .. 2r + 2 and input columns 2c - 1 .. 2c + 1 = slots vr*ROWP + 2c + dx.  Consecutive outputs of a strip share a row.
+  auto depthwise = [&](int s) {
+    const float* Pc = Pl + (s & 1) * K::PL;
+    const int c2 = tid & 15, strip = tid >> 4;
+    if (strip < K::NPART * K::WO) {
+      const int part = K::NPART > 1 && strip >= K::WO ? 1 : 0, col = strip - part * K::WO;
+      f32x2 tap[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) tap[t] = *(const f32x2*)&Pc[(3 + t) * K::KCH + 2 * c2];
+      const f32x2 dsc = *(const f32x2*)&Pc[12 * K::KCH + 2 * c2];
+      const f32x2 dbi = *(const f32x2*)&Pc[13 * K::KCH + 2 * c2];
+      const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2] - f32x2{1.f, 1.f};
+      const float* base = &El[((2 * K::RP * part) * K::ROWP + 2 * col) * K::LDE + 2 * c2];
+      unsigned* dst = (unsigned*)Dl + ((K::RP * part * K::WO + col) * 32 + 2 * c2) / 2;
+      f32x2 w0[3], w1[3], w2[3];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) w0[dx] = *(const f32x2*)(base + dx * K::LDE);
+#pragma unroll
+      for (int r = 0; r < K::RP; ++r) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          w1[dx] = *(const f32x2*)(base + ((2 * r + 1) * K::ROWP + dx) * K::LDE);
+          w2[dx] = *(const f32x2*)(base + ((2 * r + 2) * K::ROWP + dx) * K::LDE);
+        }
+        f32x2 sacc = w0[0] * tap[0];
+        sacc += w0[1] * tap[1];
+        sacc += w0[2] * tap[2];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+        f32x2 v = sacc * dsc + dbi;
+        const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
+        v = neg * dsl + v;
+        unsigned h, m, l;
+        fp_split_pair(v[0], v[1], h, m, l);
+        dst[(r * K::WO * 32) / 2] = h;
+        dst[(K::DPL + r * K::WO * 32) / 2] = m;
+        dst[(2 * K::DPL + r * K::WO * 32) / 2] = l;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) w0[dx] = w2[dx];
+      }
+    }
+  };
+
+  auto project = [&]() {
+    fp_frag3 df[2];
+    auto ldd = [&](int t, fp_frag3& d) {
+      const unsigned short* src = Dl + ((16 * t + l15) * 32 + 8 * q);
+      d.h = *(const u32x4*)src;
+      d.m = *(const u32x4*)(src + K::DPL);
+      d.l = *(const u32x4*)(src + 2 * K::DPL);
+    };
+    ldd(0, df[0]);
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      if (t + 1 < K::MTP) ldd(t + 1, df[(t + 1) & 1]);
+      const fp_frag3& d = df[t & 1];
+#pragma unroll
+      for (int j = 0; j < K::NCT; ++j) pacc[t][j] = fp_mfma_x6(pbw[j].h, pbw[j].m, pbw[j].l, d.h, d.m, d.l, pacc[t][j]);
+    }
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  __syncthreads();
+  for (int s = 0; s < R; ++s) {
+    expand(s);
+    __syncthreads();
+    load_pbw(s);
+    if (s + 1 < R) stage(s + 1);
+    depthwise(s);
+    lds_barrier();
+    project();
+    if (s + 1 < R) __syncthreads();
+  }
+
+  // ---- epilogue: output pixel o = 16 t + l15 of the band (row o / WO, column o % WO): y = acc*s + b ----
+#pragma unroll
+  for (int j = 0; j < K::NCT; ++j) {
+    const int ch = 16 * (wave * K::NCT + j) + 4 * q;
+    const f32x4 ps = *(const f32x4*)(p.paff + ch);
+    const f32x4 pb = *(const f32x4*)(p.paff + CO + ch);
+#pragma unroll
+    for (int t = 0; t < K::MTP; ++t) {
+      const int o = 16 * t + l15;
+      const f32x4 v = pacc[t][j] * ps + pb;
+      if (o < nro * K::WO) *(f32x4*)(yout + ((ro0 * K::WO + o) * CO + ch)) = v;
+    }
+  }
+}
+
+template <int CI, int G_, int CO, int HW>
+int launch_x6d(const DwbX6Args& a, hipStream_t s) {
+  using K = X6DCfg<CI, G_, CO, HW>;
+  const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6d_kernel<CI, G_, CO, HW>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+  if (ae != hipSuccess) {
+    fp_set_hip_error(ae);
+    return FP_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((dwblock_x6d_kernel<CI, G_, CO, HW>), dim3(a.N * K::NBAND), dim3(256), K::LDS_BYTES, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
 }  // namespace
 
 // Shapes the split kernel is instantiated for (include/facepath.h, DWBLOCK with FP_OPF_SPLIT3).
+static bool x6_stride2_shape(const fp_op& op) {
+  return (op.Cin == 64 && op.Cmid == 256 && op.Cout == 128 && op.H == 28) ||
+         (op.Cin == 128 && op.Cmid == 512 && op.Cout == 128 && op.H == 14);
+}
+
 bool fp_dwblock_x6_supported(const fp_op& op) {
   if (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3)) return false;
-  if (op.stride != 1 || op.KH != 3 || op.KW != 3 || op.pad_t != 1 || op.pad_l != 1) return false;
-  if (op.OH != op.H || op.OW != op.W || op.H != op.W || op.Cout != op.Cin || op.out_cmul != 1) return false;
-  const bool shape = (op.Cin == 128 && (op.H == 14 || op.H == 7)) || (op.Cin == 64 && op.H == 28);
-  if (!shape || op.Cmid != 2 * op.Cin) return false;
-  const long ns = (long)op.H * op.W * op.Cin;
-  if (op.in_ld != op.Cin || op.out_ld != op.Cout || op.in_ns != ns || op.out_ns != ns || op.in_off % 4 || op.out_off % 4) return false;
+  if ((op.stride != 1 && op.stride != 2) || op.KH != 3 || op.KW != 3 || op.pad_t != 1 || op.pad_l != 1) return false;
+  if (op.H != op.W || op.OH != op.H / op.stride || op.OW != op.W / op.stride || op.out_cmul != 1) return false;
+  if (op.stride == 1) {
+    const bool shape = (op.Cin == 128 && (op.H == 14 || op.H == 7)) || (op.Cin == 64 && op.H == 28);
+    if (!shape || op.Cout != op.Cin || op.Cmid != 2 * op.Cin) return false;
+  } else if (!x6_stride2_shape(op) || op.res_mode != FP_RES_NONE) {
+    return false;
+  }
+  const long ins = (long)op.H * op.W * op.Cin, ons = (long)op.OH * op.OW * op.Cout;
+  if (op.in_ld != op.Cin || op.out_ld != op.Cout || op.in_ns != ins || op.out_ns != ons || op.in_off % 4 || op.out_off % 4) return false;
   if (op.w_off % 4 || op.scale_off % 4 || op.slope_off % 4) return false;
   if (op.res_mode != FP_RES_NONE && op.res_mode != FP_RES_ADD_AFTER_ACT) return false;
   if (op.res_mode == FP_RES_ADD_AFTER_ACT &&
@@ -980,6 +1244,7 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   a.stagger = stagger;
   // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
   static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
+  if (op.stride == 2) return op.Cin == 64 ? launch_x6d<64, 256, 128, 28>(a, s) : launch_x6d<128, 512, 128, 14>(a, s);
   if (op.Cin == 128 && op.H == 7) return launch_x6q<7>(a, s);
   // lab knob: the wave-specialised form (matrix waves / vector waves; measured 141 against 126 us at 528 crops: its D phase
   // runs 4500 cycles beside the matrix waves' MFMAs, tools/lab/x6_lab.hip)

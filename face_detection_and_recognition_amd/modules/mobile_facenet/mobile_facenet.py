@@ -122,6 +122,13 @@ class Depth_Wise(_NoCompute):
                        npy(dw.conv.weight), _affine(dw.bn), npy(dw.prelu.weight),
                        npy(pj.conv.weight), _affine(pj.bn), y.view(), self.residual, split=True)
             return y
+        if (Depth_Wise.FUSE and Depth_Wise.X6 and expanded is None and dw.k == 3 and dw.p == 1 and not self.residual and
+                pb.dwblock_x6d_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
+            y = pb.new_buf(x.H // 2, x.W // 2, pj.out_c)
+            pb.dwblock(x, npy(ex.conv.weight), _affine(ex.bn), npy(ex.prelu.weight),
+                       npy(dw.conv.weight), _affine(dw.bn), npy(dw.prelu.weight),
+                       npy(pj.conv.weight), _affine(pj.bn), y.view(), False, split=True, stride=2)
+            return y
         if (Depth_Wise.FUSE and expanded is None and x.H in shapes and dw.k == 3 and dw.p == 1 and
                 pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
             y = pb.new_buf(x.H, x.W, pj.out_c)

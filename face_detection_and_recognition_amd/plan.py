@@ -413,24 +413,35 @@ class PlanBuilder:
 
     # shapes csrc/dwblockx6.hip (bf16x6 split MFMA, OPF_SPLIT3) is instantiated for
     DWBLOCK_X6_SHAPES = ((128, 14), (128, 7), (64, 28))
+    # ... and its stride-2 form (dwblock_x6d_kernel): (Cin, Cmid, Cout, input map size)
+    DWBLOCK_X6D_SHAPES = ((64, 256, 128, 28), (128, 512, 128, 14))
 
-    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual, split=False):
+    @classmethod
+    def dwblock_x6d_supported(cls, x, cin, cmid, cout, stride):
+        return (stride == 2 and x.H == x.W and (cin, cmid, cout, x.H) in cls.DWBLOCK_X6D_SHAPES and x.coff == 0 and x.C == cin and
+                x.buf.ld == cin and x.buf.ns == x.H * x.W * cin and not x.buf.rowpad)
+
+    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual, split=False, stride=1):
         """A whole Depth_Wise block (mobile_facenet.py:67-88) as ONE op (FP_OP_DWBLOCK, csrc/dwblock.hip): 1x1 expand
         + BN + PReLU -> dw3x3 (stride 1) + BN + PReLU -> 1x1 project + BN [+ x]; the expanded tensor stays in LDS.
         *_aff = (scale, bias) of the eval-mode BatchNorm."""
         cmid, cin = e_w.shape[0], e_w.shape[1]
         cout = pw_w.shape[0]
-        assert self.dwblock_supported(x, cin, cmid, cout, 1) and dw_w.shape == (cmid, 1, 3, 3) and pw_w.shape[1] == cmid
+        if stride == 1:
+            assert self.dwblock_supported(x, cin, cmid, cout, 1)
+        else:   # stride-2 blocks exist only in the split-MFMA form
+            assert split and not residual and self.dwblock_x6d_supported(x, cin, cmid, cout, stride)
+        assert dw_w.shape == (cmid, 1, 3, 3) and pw_w.shape[1] == cmid and (out.H, out.W) == (x.H // stride, x.W // stride)
         assert out.coff == 0 and out.C == cout and out.buf.ld == cout and out.cmul == 1 and not out.buf.rowpad
         op = self._base(L.OP_DWBLOCK, x, out, out.H, out.W)
         op.Cout, op.Cmid = cout, cmid
         op.KH = op.KW = 3
-        op.stride = 1
+        op.stride = stride
         op.pad_t = op.pad_l = 1
         op.act = L.ACT_PRELU
         if split:
             # three bf16 planes per matrix, in the fragment order of dwblock_x6_kernel (include/facepath.h, DWBLOCK)
-            assert (cin, x.H) in self.DWBLOCK_X6_SHAPES
+            assert stride == 2 or (cin, x.H) in self.DWBLOCK_X6_SHAPES
             op.flags |= L.OPF_SPLIT3
             R = cmid // 32
             e3 = split3_bf16(np.asarray(e_w, np.float32).reshape(cmid, cin))            # [3][g][k]
@@ -451,9 +462,9 @@ class PlanBuilder:
             op.res_ld, op.res_ns, op.res_off = op.in_ld, op.in_ns, op.in_off
             op.res_C, op.res_H, op.res_W = cin, x.H, x.W
         self.ops.append(op)
-        pix = x.H * x.W
+        pix, opix = x.H * x.W, out.H * out.W
         # the three convs of the block, each input once + output once
-        self.alg_bytes.append(4 * self.N * pix * ((cin + cmid) + (cmid + cmid) + (cmid + cout)))
+        self.alg_bytes.append(4 * self.N * (pix * (cin + cmid) + (pix + opix) * cmid + opix * (cmid + cout)))
         return out
 
     def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):

@@ -611,6 +611,42 @@ def test_dwblock_x6_split_mfma_vs_oracle(dev, cin, hw, residual, n):
     assert np.abs(got - ref64).max() <= 2.0 * np.abs(ref - ref64).max() + 1e-6
 
 
+@pytest.mark.parametrize("cin,cout,groups,hw,n", [
+    (64, 128, 256, 28, 3),      # conv_34: four output bands (4, 4, 4, 2 rows)
+    (64, 128, 256, 28, 70),
+    (128, 128, 512, 14, 5),     # conv_45: two bands (4, 3 rows), two row parts per depthwise strip
+    (128, 128, 512, 14, 530),
+    (64, 128, 256, 28, 530),
+])
+def test_dwblock_x6_stride2_vs_oracle(dev, cin, cout, groups, hw, n):
+    """The stride-2 Depth_Wise blocks (conv_34, conv_45; mobile_facenet.py:118,123) as ONE split-MFMA kernel
+    (dwblock_x6d_kernel) against mobilefacenet_ref._depth_wise, same bounds as the stride-1 form, plus the fp64 check."""
+    rng = np.random.default_rng(4000 + hw + n)
+    blk = Depth_Wise(cin, cout, residual=False, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=groups)
+    sd = synth_state_dict(blk.state_dict(), 1300 + cin + hw)
+    blk.load_state_dict(sd)
+    x = rng.normal(0, 1, (n, cin, hw, hw)).astype(np.float32)
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, cin)
+    y = blk.emit(pb, inp.view())
+    plan = CompiledPlan(pb, dev)
+    assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_x6d_kernel"), [plan.kernel_name(i) for i in range(plan.n_ops)]
+    t = plan.buf_tensor(inp, n)
+    t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(y, n)
+    out_t.fill_(float("nan"))
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.permute(0, 3, 1, 2).cpu().numpy()
+    ref = mobilefacenet_ref._depth_wise({k: torch.as_tensor(v) for k, v in sd.items()}, "", torch.from_numpy(x), 2, False).numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert rel_err(got, ref) < 1e-5
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+    sd64 = {k: torch.as_tensor(v).double() for k, v in sd.items()}
+    ref64 = mobilefacenet_ref._depth_wise(sd64, "", torch.from_numpy(x).double(), 2, False).numpy()
+    assert np.abs(got - ref64).max() <= 2.0 * np.abs(ref - ref64).max() + 1e-6
+
+
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
     """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through three plans (batch
     capacity 64, run on the golden's 4 images): (a) the default -- all twelve stride-1 blocks as the
@@ -633,7 +669,7 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
 
     plan = net.plan_for(64)
     ops = [plan.ops[i] for i in range(plan.n_ops)]
-    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 12
+    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 14   # + conv_34, conv_45
     e_x6 = run(plan)
     Depth_Wise.X6 = False
     try:
