@@ -948,8 +948,9 @@ int launch_x6s(const DwbX6Args& a, hipStream_t s) {
 // these blocks as pws_kernel (expand, the G-channel tensor to HBM and back) + dwpw_kernel: 317 and 251 us at 528 crops.
 template <int CI, int G_, int CO, int HW>
 struct X6DCfg {
-  static_assert((CI == 64 && G_ == 256 && CO == 128 && HW == 28) || (CI == 128 && G_ == 512 && CO == 128 && HW == 14), "");
-  static constexpr int RBO = 4;                          // output rows of a tile
+  static_assert((CI == 64 && G_ == 256 && CO == 128 && HW == 28) || (CI == 128 && G_ == 512 && CO == 128 && HW == 14) ||
+                (CI == 64 && G_ == 128 && CO == 64 && HW == 56), "");
+  static constexpr int RBO = HW == 56 ? 2 : 4;           // output rows of a tile (56-wide input: 5 x 56 expand pixels)
   static constexpr int G = G_, KCH = 32, R = G / KCH, KS = CI / 32;
   static constexpr int HO = HW / 2, WO = HW / 2;
   static constexpr int NBAND = (HO + RBO - 1) / RBO;
@@ -969,8 +970,9 @@ struct X6DCfg {
   static constexpr int NCT = CO / 64;
   static constexpr int NPART = WO <= 8 ? 2 : 1;          // depthwise strips: (row part, column)
   static constexpr int RP = RBO / NPART;                 // output rows per strip
+  static constexpr int NPASS = (NPART * WO + 15) / 16;   // passes over the strips (16 per pass)
   static constexpr int LDS_BYTES = EB * 4 + 3 * DPL * 2 + WL * 2 + 2 * PL * 4;
-  static_assert(LDS_BYTES <= 80 * 1024 && NPART * WO <= 16 && MTE <= 4 * NOWN && (WL * 2) % 4096 == 0, "");
+  static_assert(LDS_BYTES <= 80 * 1024 && MTE <= 4 * NOWN && (WL * 2) % 4096 == 0, "");
 };
 
 template <int CI, int G_, int CO, int HW>
@@ -1093,44 +1095,48 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
   // 2r .. 2r + 2 and input columns 2c - 1 .. 2c + 1 = slots vr*ROWP + 2c + dx.  Consecutive outputs of a strip share a row.
   auto depthwise = [&](int s) {
     const float* Pc = Pl + (s & 1) * K::PL;
-    const int c2 = tid & 15, strip = tid >> 4;
-    if (strip < K::NPART * K::WO) {
-      const int part = K::NPART > 1 && strip >= K::WO ? 1 : 0, col = strip - part * K::WO;
-      f32x2 tap[9];
+    const int c2 = tid & 15;
+    f32x2 tap[9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) tap[t] = *(const f32x2*)&Pc[(3 + t) * K::KCH + 2 * c2];
-      const f32x2 dsc = *(const f32x2*)&Pc[12 * K::KCH + 2 * c2];
-      const f32x2 dbi = *(const f32x2*)&Pc[13 * K::KCH + 2 * c2];
-      const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2] - f32x2{1.f, 1.f};
-      const float* base = &El[((2 * K::RP * part) * K::ROWP + 2 * col) * K::LDE + 2 * c2];
-      unsigned* dst = (unsigned*)Dl + ((K::RP * part * K::WO + col) * 32 + 2 * c2) / 2;
-      f32x2 w0[3], w1[3], w2[3];
+    for (int t = 0; t < 9; ++t) tap[t] = *(const f32x2*)&Pc[(3 + t) * K::KCH + 2 * c2];
+    const f32x2 dsc = *(const f32x2*)&Pc[12 * K::KCH + 2 * c2];
+    const f32x2 dbi = *(const f32x2*)&Pc[13 * K::KCH + 2 * c2];
+    const f32x2 dsl = *(const f32x2*)&Pc[14 * K::KCH + 2 * c2] - f32x2{1.f, 1.f};
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) w0[dx] = *(const f32x2*)(base + dx * K::LDE);
+    for (int ps = 0; ps < K::NPASS; ++ps) {
+      const int strip = (tid >> 4) + 16 * ps;
+      if (strip < K::NPART * K::WO) {
+        const int part = K::NPART > 1 && strip >= K::WO ? 1 : 0, col = strip - part * K::WO;
+        const float* base = &El[((2 * K::RP * part) * K::ROWP + 2 * col) * K::LDE + 2 * c2];
+        unsigned* dst = (unsigned*)Dl + ((K::RP * part * K::WO + col) * 32 + 2 * c2) / 2;
+        f32x2 w0[3], w1[3], w2[3];
 #pragma unroll
-      for (int r = 0; r < K::RP; ++r) {
+        for (int dx = 0; dx < 3; ++dx) w0[dx] = *(const f32x2*)(base + dx * K::LDE);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          w1[dx] = *(const f32x2*)(base + ((2 * r + 1) * K::ROWP + dx) * K::LDE);
-          w2[dx] = *(const f32x2*)(base + ((2 * r + 2) * K::ROWP + dx) * K::LDE);
+        for (int r = 0; r < K::RP; ++r) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            w1[dx] = *(const f32x2*)(base + ((2 * r + 1) * K::ROWP + dx) * K::LDE);
+            w2[dx] = *(const f32x2*)(base + ((2 * r + 2) * K::ROWP + dx) * K::LDE);
+          }
+          f32x2 sacc = w0[0] * tap[0];
+          sacc += w0[1] * tap[1];
+          sacc += w0[2] * tap[2];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+          f32x2 v = sacc * dsc + dbi;
+          const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
+          v = neg * dsl + v;
+          unsigned h, m, l;
+          fp_split_pair(v[0], v[1], h, m, l);
+          dst[(r * K::WO * 32) / 2] = h;
+          dst[(K::DPL + r * K::WO * 32) / 2] = m;
+          dst[(2 * K::DPL + r * K::WO * 32) / 2] = l;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) w0[dx] = w2[dx];
         }
-        f32x2 sacc = w0[0] * tap[0];
-        sacc += w0[1] * tap[1];
-        sacc += w0[2] * tap[2];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
-        f32x2 v = sacc * dsc + dbi;
-        const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
-        v = neg * dsl + v;
-        unsigned h, m, l;
-        fp_split_pair(v[0], v[1], h, m, l);
-        dst[(r * K::WO * 32) / 2] = h;
-        dst[(K::DPL + r * K::WO * 32) / 2] = m;
-        dst[(2 * K::DPL + r * K::WO * 32) / 2] = l;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) w0[dx] = w2[dx];
       }
     }
   };
@@ -1200,7 +1206,8 @@ int launch_x6d(const DwbX6Args& a, hipStream_t s) {
 // Shapes the split kernel is instantiated for (include/facepath.h, DWBLOCK with FP_OPF_SPLIT3).
 static bool x6_stride2_shape(const fp_op& op) {
   return (op.Cin == 64 && op.Cmid == 256 && op.Cout == 128 && op.H == 28) ||
-         (op.Cin == 128 && op.Cmid == 512 && op.Cout == 128 && op.H == 14);
+         (op.Cin == 128 && op.Cmid == 512 && op.Cout == 128 && op.H == 14) ||
+         (op.Cin == 64 && op.Cmid == 128 && op.Cout == 64 && op.H == 56);
 }
 
 bool fp_dwblock_x6_supported(const fp_op& op) {
@@ -1244,7 +1251,10 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   a.stagger = stagger;
   // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
   static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
-  if (op.stride == 2) return op.Cin == 64 ? launch_x6d<64, 256, 128, 28>(a, s) : launch_x6d<128, 512, 128, 14>(a, s);
+  if (op.stride == 2) {
+    if (op.H == 56) return launch_x6d<64, 128, 64, 56>(a, s);
+    return op.Cin == 64 ? launch_x6d<64, 256, 128, 28>(a, s) : launch_x6d<128, 512, 128, 14>(a, s);
+  }
   if (op.Cin == 128 && op.H == 7) return launch_x6q<7>(a, s);
   // lab knob: the wave-specialised form (matrix waves / vector waves; measured 141 against 126 us at 528 crops: its D phase
   // runs 4500 cycles beside the matrix waves' MFMAs, tools/lab/x6_lab.hip)

@@ -179,6 +179,9 @@ class MobileFaceNet(nn.Module):
     """mobile_facenet.py:104-154.  ``forward(x)``: (b, 3, 112, 112) float in [-1, 1] (BGR, as
     mobile_facenet/utils.py:13-17 feeds it) -> (b, embedding_size) unit-norm embeddings."""
 
+    # conv2_dw + conv_23: True = depthwise launch + whole-block split-MFMA kernel; False = the round-2 pair of dw->pw kernels
+    X6_CONV23 = True
+
     def __init__(self, embedding_size):
         super().__init__()
         self.embedding_size = embedding_size
@@ -218,7 +221,14 @@ class MobileFaceNet(nn.Module):
         inp = pb.new_buf(H, W, 3)
         x = self.conv1.emit(pb, inp.view())
         c2, c23 = self.conv2_dw, self.conv_23
-        if Depth_Wise.FUSE and c2.k == 3 and c2.s == 1 and c2.p == 1 and c2.groups % 64 == 0 and not c23.residual:
+        if (Depth_Wise.FUSE and Depth_Wise.X6 and MobileFaceNet.X6_CONV23 and c23.conv_dw.s == 2 and not c23.residual and
+                x.H == x.W and c2.out_c == c23.conv.in_c and
+                (c23.conv.in_c, c23.conv.out_c, c23.project.out_c, x.H) in pb.DWBLOCK_X6D_SHAPES):
+            # conv2_dw as a plain depthwise launch, then ALL of conv_23 (expand -> dw stride 2 -> project) as one
+            # split-MFMA kernel: the 128-channel 56x56 tensor (848 MB at 528 crops) never exists
+            y = c2.emit(pb, x.view()); pb.free(x); x = y
+            y = c23.emit(pb, x.view()); pb.free(x); x = y
+        elif Depth_Wise.FUSE and c2.k == 3 and c2.s == 1 and c2.p == 1 and c2.groups % 64 == 0 and not c23.residual:
             # conv2_dw (dw3x3 + BN + PReLU) -> conv_23.conv (1x1 + BN + PReLU) as ONE dw->pw kernel: the 64-channel
             # 56x56 tensor between them (873 MB at N = 1088) never goes to HBM
             ex = c23.conv
@@ -266,7 +276,7 @@ class MobileFaceNet(nn.Module):
         shapes = Depth_Wise.BLOCK_SHAPES if Depth_Wise.BLOCK_SHAPES is not None else \
             Depth_Wise.block_policy(N if n_run is None else n_run)
         shapes = tuple(shapes)
-        return self._plans.get((N, shapes, Depth_Wise.FUSE, Depth_Wise.X6), lambda cache: self._build(N, cache, block_shapes=shapes))
+        return self._plans.get((N, shapes, Depth_Wise.FUSE, Depth_Wise.X6, MobileFaceNet.X6_CONV23), lambda cache: self._build(N, cache, block_shapes=shapes))
 
     def forward(self, x):
         b = x.shape[0]

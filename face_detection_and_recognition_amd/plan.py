@@ -414,7 +414,7 @@ class PlanBuilder:
     # shapes csrc/dwblockx6.hip (bf16x6 split MFMA, OPF_SPLIT3) is instantiated for
     DWBLOCK_X6_SHAPES = ((128, 14), (128, 7), (64, 28))
     # ... and its stride-2 form (dwblock_x6d_kernel): (Cin, Cmid, Cout, input map size)
-    DWBLOCK_X6D_SHAPES = ((64, 256, 128, 28), (128, 512, 128, 14))
+    DWBLOCK_X6D_SHAPES = ((64, 256, 128, 28), (128, 512, 128, 14), (64, 128, 64, 56))
 
     @classmethod
     def dwblock_x6d_supported(cls, x, cin, cmid, cout, stride):

@@ -455,7 +455,7 @@ def test_mobilefacenet_fused_and_unfused_plans_agree(dev):
             net = net.to(dev)
             plan = net.plan_for(4)
             kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
-            assert (L.OP_DWPW in kinds) == fuse
+            assert (L.OP_DWPW in kinds or L.OP_DWBLOCK in kinds) == fuse   # fused forms: dw->pw kernels / whole-block kernels
             outs[fuse] = net(torch.from_numpy(g["x"])).cpu().numpy().copy()
         finally:
             Depth_Wise.FUSE = True
@@ -617,6 +617,8 @@ def test_dwblock_x6_split_mfma_vs_oracle(dev, cin, hw, residual, n):
     (128, 128, 512, 14, 5),     # conv_45: two bands (4, 3 rows), two row parts per depthwise strip
     (128, 128, 512, 14, 530),
     (64, 128, 256, 28, 530),
+    (64, 64, 128, 56, 3),       # conv_23: fourteen bands of two output rows, two column passes in the depthwise phase
+    (64, 64, 128, 56, 130),
 ])
 def test_dwblock_x6_stride2_vs_oracle(dev, cin, cout, groups, hw, n):
     """The stride-2 Depth_Wise blocks (conv_34, conv_45; mobile_facenet.py:118,123) as ONE split-MFMA kernel
@@ -669,7 +671,7 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
 
     plan = net.plan_for(64)
     ops = [plan.ops[i] for i in range(plan.n_ops)]
-    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 14   # + conv_34, conv_45
+    assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 15   # + conv_23, conv_34, conv_45
     e_x6 = run(plan)
     Depth_Wise.X6 = False
     try:

@@ -14,7 +14,7 @@ from face_detection_and_recognition_amd.synth import synth_state_dict  # noqa: E
 
 def build(hw, n, x6, dev, stride=1):
     cin = {28: 64, 14: 128, 7: 128, 56: 64}[hw]
-    cout, groups = (cin, 2 * cin) if stride == 1 else (128, 4 * cin)
+    cout, groups = (cin, 2 * cin) if stride == 1 or hw == 56 else (128, 4 * cin)
     blk = Depth_Wise(cin, cout, residual=stride == 1, kernel=(3, 3), stride=(stride, stride), padding=(1, 1), groups=groups)
     blk.load_state_dict(synth_state_dict(blk.state_dict(), 5))
     pb = PlanBuilder(n)
@@ -49,7 +49,7 @@ def main():
     for a in args:
         stride = 2 if a.startswith("s2:") else 1
         hw, n = (int(v) for v in a.replace("s2:", "").split(":"))
-        cin = {28: 64, 14: 128, 7: 128}[hw]
+        cin = {28: 64, 14: 128, 7: 128, 56: 64}[hw]
         flop = 2.0 * n * hw * hw * cin * 2 * cin * 2 if stride == 1 else 2.0 * n * (hw * hw * cin * 4 * cin + hw * hw / 4 * 4 * cin * 128)
         row = []
         for x6 in (True, False):
