@@ -40,6 +40,8 @@ from face_detection_and_recognition_amd import workload as W  # noqa: E402
 from face_detection_and_recognition_amd.pipeline import FacePipeline  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (= the fp32 vector rate); SURVEY 8(d)'s fp32 roofline
+BF16_MFMA_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak
 MFMA_F32_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 B_FRAMES = 256
 N_BATCHES = 4              # distinct frame batches the timed steps rotate through
@@ -286,7 +288,7 @@ def run_pipeline(args):
         # output once (plan.compulsory_bytes; a fused op is not charged for tensors that never exist) -- so frac <= 1 by
         # construction.  OP-GRANULAR (`op_granular_*`): SURVEY 8(d)'s model, every conv of the reference reads its input
         # and writes its output; a fused kernel beats it by design (values > 1 there measure fusion, not bandwidth).
-        ms_tot, launches, alg_tot, phys_tot, pipe_alg, pipe_phys = 0.0, 0, 0.0, 0.0, 0.0, 0.0
+        ms_tot, launches, alg_tot, phys_tot, pipe_alg, pipe_phys, flop_tot, dom_bound = 0.0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, "hbm"
         for k in range(args.steps):
             n_k = faces_per_step[k]
             n_pad = (n_k + pipe.bucket - 1) // pipe.bucket * pipe.bucket
@@ -306,6 +308,8 @@ def run_pipeline(args):
                         launches += 1
                         alg_tot += p.algorithmic_bytes(i) * real
                         phys_tot += p.compulsory_bytes(i, n_run)
+                        flop_tot += p.flops(i, n_run)
+                        dom_bound = p.bound(i)
         pipe_alg = pipe_alg / args.steps + B_FRAMES * (FRAME_BYTES + LETTERBOX_OUT_BYTES)
         pipe_phys = pipe_phys / args.steps
         achieved = phys_tot / (ms_tot * 1e-3) / 1e9 if ms_tot > 0 else 0.0
@@ -333,6 +337,20 @@ def run_pipeline(args):
                          "output once; tensors inside a fused op are not counted) / HIP-event time / 8 TB/s; op_granular_*: "
                          "SURVEY 8(d)'s model (every reference conv reads its input and writes its output), which a fused "
                          "kernel beats by design; hbm_frac_from_traffic: PMC bytes of the committed profile / launch time"}
+        if dom_bound == "mfma":
+            # the dominant family is a split-MFMA block: bound by matrix-core issue, not by HBM.  achieved = the reference's
+            # conv FLOPs of the launch / HIP-event time; peak = the fp32 matrix peak SURVEY 8(d) prices fp32 GEMMs at;
+            # matrix_pipe_frac = the bf16 MFMA work actually issued (six products per fp32 product) / the bf16 peak
+            tf = flop_tot / (ms_tot * 1e-3) / 1e12 if ms_tot > 0 else 0.0
+            roof.update({"bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+                         "matrix_pipe_frac": round(6.0 * tf / BF16_MFMA_PEAK_TF, 4),
+                         "hbm_GBps": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "flops_per_launch": int(flop_tot / max(launches, 1))})
+            roof["model"] = ("bound mfma: achieved = reference conv FLOPs of the launch (fp32 semantics) / HIP-event time, peak = "
+                             "fp32 matrix peak 157.3 TF/s (the rate SURVEY 8(d) prices fp32 GEMMs at; the kernel computes them as "
+                             "six bf16 products each on the bf16 pipe: matrix_pipe_frac = 6 x achieved / 2.5 PF); hbm_*: "
+                             "compulsory bytes / time; " + roof["model"])
 
     # ---- the same step with every GEMM on the fp32 MFMA (outside the timed region; rank 0, N = 1) ----
     arith = None

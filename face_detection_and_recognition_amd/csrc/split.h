@@ -10,10 +10,12 @@
 // keep the six whose weight is >= 2^-16 of the product,
 //     ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm),
 // and drop am*bl + al*bm + al*bl <= 2^-23 |a*b| -- the size of ONE fp32 rounding.  Accumulation is fp32 as before.
-// Measured through the whole Mobile-FaceNet (tools/split_precision.py, fp64 as the truth): max |embedding error|
+// Measured through the whole Mobile-FaceNet (tests/test_split_precision.py, fp64 as the truth): max |embedding error|
 // 2.1e-7 for this scheme against 3.3e-7 for the fp32 fmaf chain; a two-piece split (three products) gives 3.5e-5 and
-// is NOT used.  Cost: 6 MFMAs of 16 cycles per 16x16x32 block against 16 of 32 cycles (16x16x4 f32) = 5.3x fewer
-// matrix cycles, and the VALU is free meanwhile.
+// is NOT used.  Cost: 6 MFMAs of ~18 cycles per 16x16x32 block (tools/lab/coexec_bf16_lab.hip) against 16 of 32 cycles
+// (16x16x4 f32) = 4.7x fewer matrix cycles, and each MFMA holds the SIMD's issue port for only ~8 of them: the VALU of
+// the partner wave gets about two instructions in per MFMA (v_fma_f32 8.7 cycles beside MFMAs, 6.3 alone; v_pk_fma_f32
+// 22.5 against 9.0).
 // Weights are split once on the host (plan.py split3_bf16); activations in registers where they are produced.
 #pragma once
 #include "common.h"

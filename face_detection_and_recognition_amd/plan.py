@@ -761,6 +761,30 @@ class CompiledPlan:
                                                                  # ops' shortcut is their input: read once)
         return n * (b_in + b_out + b_res)
 
+    def flops(self, i, n=None):
+        """Arithmetic of op i as the REFERENCE counts it (2 x multiply-accumulates of its convolutions, logical shapes) for a
+        batch of n images -- whatever instructions the kernel uses for them."""
+        op = self.ops[i]
+        n = self.n_run if n is None else n
+        k, opix = op.kind, op.OH * op.OW
+        if k in (L.OP_CONV, L.OP_STEM_U8):
+            f = opix * op.KH * op.KW * op.Cin * op.Cout
+        elif k == L.OP_DWCONV:
+            f = opix * op.KH * op.KW * op.Cin
+        elif k in (L.OP_BLAZEBLOCK, L.OP_DWPW):
+            f = opix * (9 * op.Cin + op.Cin * op.Cout)
+        elif k == L.OP_BLAZEPAIR:
+            f = 2 * opix * (9 * op.Cin + op.Cin * op.Cout)
+        elif k == L.OP_DWBLOCK:
+            f = op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cout)
+        else:
+            f = 0
+        return 2.0 * n * f
+
+    def bound(self, i):
+        """"mfma" for the ops whose kernels run on the matrix cores near their issue limit (the split-MFMA blocks), else "hbm"."""
+        return "mfma" if self.ops[i].flags & L.OPF_SPLIT3 else "hbm"
+
     def algorithmic_bytes(self, i):
         """Op-granular fp32 activation bytes of op i: a conv / linear reads its input once and
         writes its output once (logical channel counts); epilogue-class ops (bias, BN, activation, residual,

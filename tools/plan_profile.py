@@ -29,19 +29,7 @@ def profile(plan, name, reps=10):
         op = plan.ops[i]
         t = ms[i] / reps
         gb = plan.algorithmic_bytes(i) / 1e9
-        fl = 0
-        if op.kind == L.OP_CONV:
-            fl = 2.0 * op.N * op.OH * op.OW * op.KH * op.KW * op.Cin * op.Cout
-        elif op.kind == L.OP_DWCONV:
-            fl = 2.0 * op.N * op.OH * op.OW * op.KH * op.KW * op.Cin
-        elif op.kind == L.OP_BLAZEBLOCK:
-            fl = 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
-        elif op.kind == L.OP_BLAZEPAIR:
-            fl = 2 * 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
-        elif op.kind == L.OP_DWPW:
-            fl = 2.0 * op.N * op.OH * op.OW * (9 * op.Cin + op.Cin * op.Cout)
-        elif op.kind == L.OP_DWBLOCK:
-            fl = 2.0 * op.N * op.OH * op.OW * (op.Cin * op.Cmid + 9 * op.Cmid + op.Cmid * op.Cout)
+        fl = plan.flops(i)
         print(f"{i:3d} {plan.kernel_name(i):34s} {op.H:4d}x{op.W:<4d} {op.Cin:4d}->{op.Cout:<4d} k{op.KH} s{op.stride} "
               f"{t * 1e3:9.1f} us {100 * t / tot:5.1f}%  {gb / (t * 1e-3 + 1e-12):8.0f} GB/s {fl / (t * 1e-3 + 1e-12) / 1e12:6.1f} TF/s")
 

@@ -23,7 +23,7 @@ def short(name):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
-    cmd = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+    cmd = sys.argv[5] if len(sys.argv) > 5 else "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg"
     os.makedirs("profiles", exist_ok=True)
     ks = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0]
     shutil.copy(ks, f"profiles/{tag}_kernel_stats.csv")

@@ -9,7 +9,7 @@ set -e
 tag=$1
 rm -rf gpurun_out/${tag}_bench_stats gpurun_out/${tag}_bench_fetch gpurun_out/${tag}_bench_write
 rm -rf gpurun_out/${tag}_yolo_stats gpurun_out/${tag}_yolo_fetch gpurun_out/${tag}_yolo_write
-timeout -k 10 500 tools/collect_profiles.sh ${tag}_bench bench.py --steps 10 --warmup 3 --no-cpu-baseline
+timeout -k 10 500 tools/collect_profiles.sh ${tag}_bench bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg
 echo "[refresh] bench profiles done"
 timeout -k 10 500 tools/collect_profiles.sh ${tag}_yolo tools/config_bench.py yolov5n yolov5s
 echo "[refresh] yolo profiles done"
