@@ -90,6 +90,9 @@ bool fp_dwblock_x6_supported(const fp_op& op);   // DWBLOCK with FP_OPF_SPLIT3: 
 long fp_dwblock_x6_we_floats(const fp_op& op);   // floats behind w_off / slope_off of such an op
 long fp_dwblock_x6_wp_floats(const fp_op& op);
 int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_pwx6_eligible(const fp_op& op);     // CONV with FP_OPF_SPLIT3: pointwise conv on the bf16x6 split-MFMA kernel (pwx6.hip)
+long fp_pwx6_w_floats(const fp_op& op);
+int fp_launch_pwx6(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pws_eligible(const fp_op& op);      // pointwise K = 64 convs that take the wave-private streaming kernel
 int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)

@@ -1,0 +1,233 @@
+// pwx6.hip — pointwise (1x1) convolution on the bf16 matrix cores with fp32-equivalent arithmetic (split.h) — gfx950.
+//
+// The 1x1 convs with K >= 128 input channels (YOLOv5-face's C3 / ShuffleV2 / PAN convs, y5/models/common.py:35-56,127-176;
+// Mobile-FaceNet's conv_6_sep, mobile_facenet.py:131) are bound by the fp32 MFMA in conv_igemm_kernel (~100 TFLOP/s =
+// 65 % of the 157 TFLOP/s fp32 matrix peak, which is the fp32 VECTOR rate, DESIGN finding 18).  Here the fp32 operands are
+// split exactly into three bf16 pieces each and multiplied as six bf16 MFMAs per product (fp32 accumulation, csrc/split.h):
+//   * a workgroup = 4 waves owns 256 consecutive rows (pixels) x one chunk of <= 128 output channels; a wave owns 64 rows
+//     (four 16-row MFMA tiles) for ALL of the chunk's columns: accumulators 4 x 8 x 4 registers, A split ONCE per element;
+//   * K runs in slabs of 32: a wave's A slab comes straight from global memory into registers (lane = (row, 8 consecutive k):
+//     two 16-byte loads), is split there (5.5 VALU per element, beside the MFMAs) -- no LDS for A;
+//   * the weight slab [3 planes][chunk columns][32 k] bf16 (pre-split on the host, plan.py) is staged by LDS-DMA, double
+//     buffered, one workgroup barrier per slab; every wave reads each 16-column fragment once per slab and uses it for its
+//     four row tiles (24 MFMAs per 3 ds_read_b128);
+//   * operands swapped (D^T = W^T A^T): a lane ends up with 4 consecutive channels of ONE pixel -- 16-byte epilogue
+//     (scale / bias, residual, ReLU / PReLU / SiLU, ShuffleV2's interleaved store) straight from the accumulators.
+// Eligibility (fp_pwx6_eligible) mirrors plan.py's PlanBuilder.pwx6_ok: the op carries FP_OPF_SPLIT3 and split weights.
+#include <string.h>
+
+#include "split.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_ptr;
+
+struct PwX6Args {
+  const float* in;
+  float* out;
+  const float* res;
+  const unsigned short* w;   // [K / 32][3][N][32] bf16
+  const float* scale;
+  const float* bias;
+  const float* slope;
+  long M;                    // rows = N * H * W
+  int K, N, in_ld, out_ld, res_ld, res_C, act, res_mode;
+};
+
+constexpr int MT = 4;        // 16-row tiles per wave
+constexpr int BM = 4 * MT * 16;
+
+// NT16 = 16-column tiles of a column chunk (3: N = 48, 4: N = 64, 8: chunks of 128)
+template <int NT16>
+__global__ __launch_bounds__(256, 2) void pwx6_kernel(PwX6Args p) {
+  constexpr int NC = NT16 * 16;
+  constexpr int SLAB = 3 * NC * 32;                      // bf16 elements of a weight slab
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Bl = (unsigned short*)smem_raw;        // [2][3][NC][32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int nchunk = p.N / NC;
+  const int chunk = blockIdx.x % nchunk;                 // column chunks of one row tile sit next to each other (A re-read from L2)
+  const long row0 = (long)(blockIdx.x / nchunk) * BM + wave * (MT * 16);
+  const int c0 = chunk * NC;
+  const int KS = p.K / 32;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  // weight slab ks -> Bl[ks & 1]: three planes of NC x 64 bytes, 1 KiB per wave and instruction
+  auto stage = [&](int ks) {
+    unsigned char* dst = (unsigned char*)(Bl + (ks & 1) * SLAB);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned char* src = (const unsigned char*)(p.w + ((long)(ks * 3 + pl) * p.N + c0) * 32) + lane * 16;
+#pragma unroll
+      for (int j = 0; j < (NT16 + 3) / 4; ++j) {
+        const int c = j * 4 + wave;                      // 1-KiB piece = 16 columns
+        if (c < NT16)
+          __builtin_amdgcn_global_load_lds((gbl_ptr)(src + c * 1024), (lds_ptr)(dst + (pl * NC * 32 + c * 512) * 2), 16, 0, 0);
+      }
+    }
+  };
+
+  // this lane's rows: tile t -> row row0 + 16 t + l15 (clamped), k = 32 ks + 8 q .. + 7
+  const float* arow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    long r = row0 + 16 * t + l15;
+    r = r < p.M ? r : p.M - 1;
+    arow[t] = p.in + r * p.in_ld + 8 * q;
+  }
+  f32x4 araw[MT][2];
+  auto load_a = [&](int ks) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      araw[t][0] = *(const f32x4*)(arow[t] + 32 * ks);
+      araw[t][1] = *(const f32x4*)(arow[t] + 32 * ks + 4);
+    }
+  };
+
+  f32x4 acc[MT][NT16];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) acc[t][n] = z;
+
+  stage(0);
+  load_a(0);
+  for (int ks = 0; ks < KS; ++ks) {
+    fp_frag3 af[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) af[t] = fp_split8(araw[t][0], araw[t][1]);
+    __syncthreads();   // slab ks landed (own DMA waited for, then everybody's); every wave is done with slab ks - 1
+    if (ks + 1 < KS) {
+      stage(ks + 1);
+      load_a(ks + 1);
+    }
+    const unsigned short* Bc = Bl + (ks & 1) * SLAB + (l15 * 32 + 8 * q);
+    fp_frag3 bf[2];
+    auto ldb = [&](int n, fp_frag3& b) {
+      b.h = *(const u32x4*)(Bc + n * 512);
+      b.m = *(const u32x4*)(Bc + NC * 32 + n * 512);
+      b.l = *(const u32x4*)(Bc + 2 * NC * 32 + n * 512);
+    };
+    ldb(0, bf[0]);
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) {
+      if (n + 1 < NT16) ldb(n + 1, bf[(n + 1) & 1]);
+      const fp_frag3& b = bf[n & 1];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][n] = fp_mfma_x6(b.h, b.m, b.l, af[t].h, af[t].m, af[t].l, acc[t][n]);
+    }
+  }
+
+  // ---- epilogue: lane = row 16 t + l15, channels c0 + 16 n + 4 q .. + 3 ----
+  const bool shuffle = p.res_mode == FP_RES_SHUFFLE2;
+#pragma unroll
+  for (int n = 0; n < NT16; ++n) {
+    const int ch = c0 + 16 * n + 4 * q;
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+    const f32x4 sc = p.scale ? *(const f32x4*)(p.scale + ch) : one;
+    const f32x4 bi = p.bias ? *(const f32x4*)(p.bias + ch) : z;
+    const f32x4 sl = p.act == FP_ACT_PRELU ? *(const f32x4*)(p.slope + ch) : z;
+    f32x4 rv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      long r = row0 + 16 * t + l15;
+      r = r < p.M ? r : p.M - 1;
+      rv[t] = z;
+      if (p.res_mode != FP_RES_NONE) {
+        // channels beyond res_C add 0 (res_C is a multiple of 4 for every eligible op)
+        if (ch < p.res_C) rv[t] = *(const f32x4*)(p.res + r * p.res_ld + ch);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const long r = row0 + 16 * t + l15;
+      f32x4 v = acc[t][n] * sc + bi;
+      if (p.res_mode == FP_RES_ADD_BEFORE_ACT) v += rv[t];
+      if (p.act == FP_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+      } else if (p.act == FP_ACT_PRELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * sl[i];
+      } else if (p.act == FP_ACT_SILU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fp_silu(v[i]);
+      }
+      if (p.res_mode == FP_RES_ADD_AFTER_ACT) v += rv[t];
+      if (r < p.M) {
+        if (shuffle) {   // out[2 c] = res[c], out[2 c + 1] = act(conv)[c]: two 16-byte pieces
+          float* o = p.out + r * p.out_ld + 2 * ch;
+          *(f32x4*)o = f32x4{rv[t][0], v[0], rv[t][1], v[1]};
+          *(f32x4*)(o + 4) = f32x4{rv[t][2], v[2], rv[t][3], v[3]};
+        } else {
+          *(f32x4*)(p.out + r * p.out_ld + ch) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT16>
+int launch(const PwX6Args& a, hipStream_t s) {
+  constexpr int lds = 2 * 3 * NT16 * 16 * 32 * 2;
+  const long tiles = (a.M + BM - 1) / BM * (a.N / (NT16 * 16));
+  if (tiles >= (1L << 31)) return FP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((pwx6_kernel<NT16>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+int chunk_tiles(int N) { return N == 48 ? 3 : N == 64 ? 4 : (N % 128 == 0 ? 8 : 0); }
+
+}  // namespace
+
+// A CONV that carries FP_OPF_SPLIT3: pointwise on dense rows, K a multiple of 32 (>= 64), Cout 48 / 64 / a multiple of 128,
+// 16-byte aligned views, residual modes none / add before / add after / ShuffleV2 interleave.
+bool fp_pwx6_eligible(const fp_op& op) {
+  if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3) || (op.flags & ~FP_OPF_SPLIT3)) return false;
+  if (op.KH != 1 || op.KW != 1 || op.stride != 1 || op.pad_t || op.pad_l || op.OH != op.H || op.OW != op.W) return false;
+  if (op.Cin % 32 || op.Cin < 64 || chunk_tiles(op.Cout) == 0 || op.out_cmul != 1) return false;
+  const long HW = (long)op.H * op.W;
+  if (op.in_ns != HW * op.in_ld || op.out_ns != HW * op.out_ld) return false;
+  if (op.in_ld % 4 || op.in_off % 4 || op.out_ld % 4 || op.out_off % 4 || op.w_off % 4) return false;
+  if ((op.scale_off >= 0 && op.scale_off % 4) || (op.bias_off >= 0 && op.bias_off % 4) || (op.slope_off >= 0 && op.slope_off % 4)) return false;
+  if (op.act == FP_ACT_PRELU && op.slope_off < 0) return false;
+  if (op.res_mode != FP_RES_NONE) {
+    if (op.res_mode == FP_RES_POOL2_BEFORE_ACT) return false;
+    if (op.res_ns != HW * op.res_ld || op.res_ld % 4 || op.res_off % 4 || op.res_C % 4) return false;
+    if (op.res_mode == FP_RES_SHUFFLE2 && (op.res_C < op.Cout || op.out_ld < 2 * op.Cout)) return false;
+  }
+  return true;
+}
+
+long fp_pwx6_w_floats(const fp_op& op) { return (long)op.Cin * op.Cout * 3 / 2; }
+
+int fp_launch_pwx6(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  if (!fp_pwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
+  PwX6Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.res = op.res_mode != FP_RES_NONE ? arena + op.res_off : nullptr;
+  a.w = (const unsigned short*)(weights + op.w_off);
+  a.scale = op.scale_off >= 0 ? weights + op.scale_off : nullptr;
+  a.bias = op.bias_off >= 0 ? weights + op.bias_off : nullptr;
+  a.slope = op.slope_off >= 0 ? weights + op.slope_off : nullptr;
+  a.M = (long)op.N * op.H * op.W;
+  a.K = op.Cin;
+  a.N = op.Cout;
+  a.in_ld = op.in_ld;
+  a.out_ld = op.out_ld;
+  a.res_ld = op.res_ld;
+  a.res_C = op.res_C;
+  a.act = op.act;
+  a.res_mode = op.res_mode;
+  switch (chunk_tiles(op.Cout)) {
+    case 3: return launch<3>(a, s);
+    case 4: return launch<4>(a, s);
+    default: return launch<8>(a, s);
+  }
+}

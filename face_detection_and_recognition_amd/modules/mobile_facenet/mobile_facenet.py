@@ -72,7 +72,19 @@ class Linear_block(_NoCompute):
         return y
 
 
-class Depth_Wise(_NoCompute):
+class _X6Switch(type(_NoCompute)):
+    """``Depth_Wise.X6`` reads / writes PlanBuilder.X6: one switch for every split-MFMA kernel."""
+
+    @property
+    def X6(cls):
+        return PlanBuilder.X6
+
+    @X6.setter
+    def X6(cls, value):
+        PlanBuilder.X6 = bool(value)
+
+
+class Depth_Wise(_NoCompute, metaclass=_X6Switch):
     """1x1 expand (PReLU) -> depthwise 3x3 stride s (PReLU) -> 1x1 project (BN only) [+ x]
     (mobile_facenet.py:67-88)."""
 
@@ -87,10 +99,10 @@ class Depth_Wise(_NoCompute):
     # Whole block as ONE kernel (FP_OP_DWBLOCK, csrc/dwblock.hip) on the map sizes in BLOCK_SHAPES; None = block_policy
     # of the batch the plan will run on.  Tests pin it to a tuple.
     BLOCK_SHAPES = None
-    # Stride-1 blocks on the 14x14 and 28x28 maps as ONE kernel on the bf16 matrix cores with fp32-equivalent arithmetic
-    # (FP_OP_DWBLOCK + OPF_SPLIT3, csrc/dwblockx6.hip, csrc/split.h: exact three-way operand split, six products).
-    # False = every GEMM on the fp32 MFMA (the fmaf-chain kernels of rounds 1-3).
-    X6 = True
+    # Depth_Wise.X6 (class attribute, = PlanBuilder.X6): every Depth_Wise block as ONE kernel on the bf16 matrix cores with
+    # fp32-equivalent arithmetic (FP_OP_DWBLOCK + OPF_SPLIT3, csrc/dwblockx6.hip, csrc/split.h: exact three-way operand
+    # split, six products), and the K >= 128 pointwise convs on csrc/pwx6.hip.  False = every GEMM on the fp32 MFMA (the
+    # fmaf-chain kernels of rounds 1-3).
 
     @staticmethod
     def block_policy(n):

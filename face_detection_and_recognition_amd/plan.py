@@ -251,6 +251,35 @@ class PlanBuilder:
                 op.flags |= bit
         return op
 
+    # Pointwise convs with K >= PW_X6_MIN_K input channels on the bf16x6 split-MFMA kernel (csrc/pwx6.hip); 0 = never.
+    # Below 128 channels the fp32-MFMA kernels already run at the HBM rate of these shapes.
+    PW_X6_MIN_K = 128
+    # Master switch of the bf16x6 split-MFMA kernels (csrc/split.h): False = every GEMM on the fp32 MFMA (the fmaf-chain
+    # kernels of rounds 1-3).  Mobile-FaceNet's Depth_Wise.X6 is this attribute.
+    X6 = True
+
+    @classmethod
+    def pwx6_ok(cls, x, out, kh, kw, stride, pad, res, res_mode):
+        """Mirror of fp_pwx6_eligible (csrc/pwx6.hip) + the size policy above."""
+        if not cls.X6 or not cls.PW_X6_MIN_K or x.C < cls.PW_X6_MIN_K:
+            return False
+        if (kh, kw, stride) != (1, 1, 1) or tuple(pad) != (0, 0) or (out.H, out.W) != (x.H, x.W):
+            return False
+        if x.C % 32 or not (out.C in (48, 64) or out.C % 128 == 0) or out.cmul != 1 or x.buf.rowpad or out.buf.rowpad:
+            return False
+        hw = x.H * x.W
+        views = [x, out] + ([res] if res_mode != L.RES_NONE else [])
+        for v in views:
+            if v.buf.ns != hw * v.buf.ld or v.buf.ld % 4 or (v.buf.off + v.coff) % 4:
+                return False
+        if res_mode == L.RES_POOL2_BEFORE_ACT:
+            return False
+        if res_mode != L.RES_NONE and min(res.C, out.C) % 4:
+            return False
+        if res_mode == L.RES_SHUFFLE2 and (res.C < out.C or out.buf.ld < 2 * out.C):
+            return False
+        return True
+
     def conv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None,
              act=L.ACT_NONE, res=None, res_mode=L.RES_NONE, n_convs=1):
         """Dense conv (OIHW weight); out is a View whose C >= Cout (extra channels get zeros)."""
@@ -262,7 +291,15 @@ class PlanBuilder:
         op.KH, op.KW, op.stride = kh, kw, stride
         op.pad_t, op.pad_l = pad
         op.act, op.res_mode = act, res_mode
-        op.w_off = self.add_weight(pack_conv_weight(w, x.C, out.C))
+        if self.pwx6_ok(x, out, kh, kw, stride, pad, res, res_mode) and not op.flags:
+            # three bf16 planes [K / 32][3][N][32] (include/facepath.h, FP_OPF_SPLIT3 on FP_OP_CONV)
+            full = np.zeros((out.C, x.C), np.float32)
+            full[:cout, :cin] = np.asarray(w, np.float32).reshape(cout, cin)
+            w3 = split3_bf16(full).reshape(3, out.C, x.C // 32, 32).transpose(2, 0, 1, 3)
+            op.w_off = self.add_weight(np.ascontiguousarray(w3).reshape(-1).view(np.float32))
+            op.flags |= L.OPF_SPLIT3
+        else:
+            op.w_off = self.add_weight(pack_conv_weight(w, x.C, out.C))
         if cin == 3 and x.C == 4 and x.buf.ld == 4:   # 3-channel image padded to 16-byte pixels: the pad channel's weights are zero
             op.flags |= L.OPF_IN_C3
         if scale is not None:

@@ -4,6 +4,7 @@ and cosine scores (BASELINE.json north_star); activations compared with a 1e-4 r
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import golden, rel_err
 from face_detection_and_recognition_amd import _lib as L
@@ -647,6 +648,74 @@ def test_dwblock_x6_stride2_vs_oracle(dev, cin, cout, groups, hw, n):
     sd64 = {k: torch.as_tensor(v).double() for k, v in sd.items()}
     ref64 = mobilefacenet_ref._depth_wise(sd64, "", torch.from_numpy(x).double(), 2, False).numpy()
     assert np.abs(got - ref64).max() <= 2.0 * np.abs(ref - ref64).max() + 1e-6
+
+
+@pytest.mark.parametrize("k,n,act,res_mode,shape,in_slice", [
+    (128, 128, "silu", "none", (3, 20, 20), 0),        # ragged row tile (1200 rows), one chunk
+    (256, 128, "silu", "none", (2, 40, 40), 128),      # input = channel slice [128, 384) of a 384-channel concat buffer
+    (384, 128, "silu", "none", (1, 17, 23), 0),        # 12 K slabs, rows not a multiple of 16
+    (128, 48, "none", "none", (4, 20, 20), 0),         # Detect head: three 16-column tiles
+    (256, 64, "relu", "after", (2, 16, 16), 0),        # residual added after the activation
+    (128, 64, "none", "before", (2, 16, 16), 0),       # ... before it
+    (256, 256, "silu", "shuffle", (2, 20, 20), 0),     # ShuffleV2 tail: out[2c] = res[c], out[2c + 1] = conv[c]; two chunks
+    (128, 512, "prelu", "none", (70, 7, 7), 0),        # Mobile-FaceNet conv_6_sep: four column chunks
+    (512, 512, "none", "none", (530, 1, 1), 0),        # the embedding Linear as a 1x1 conv: 16 slabs, M = 530 rows
+])
+def test_pwx6_pointwise_conv_vs_torch(dev, k, n, act, res_mode, shape, in_slice):
+    """csrc/pwx6.hip (pointwise conv on the bf16x6 split MFMA, FP_OP_CONV + FP_OPF_SPLIT3) against torch's fp32 conv2d /
+    epilogue arithmetic on the CPU, over the epilogue forms and view shapes YOLOv5-face and Mobile-FaceNet use; bounds as
+    for the fp32-MFMA kernels (1e-5 of the output scale) + the fp64 check of the split arithmetic."""
+    N, H, W = shape
+    rng = np.random.default_rng(k * 7 + n)
+    cin_phys = k + in_slice + (64 if in_slice else 0)
+    x = rng.normal(0, 1, (N, cin_phys, H, W)).astype(np.float32)
+    w = rng.normal(0, (2.0 / k) ** 0.5, (n, k, 1, 1)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    bias = rng.normal(0, 0.2, n).astype(np.float32)
+    slope = rng.uniform(0.1, 0.3, n).astype(np.float32)
+    r = rng.normal(0, 1, (N, n, H, W)).astype(np.float32)
+    pb = PlanBuilder(N)
+    xb = pb.new_buf(H, W, cin_phys)
+    ob = pb.new_buf(H, W, 2 * n if res_mode == "shuffle" else n)
+    rb = pb.new_buf(H, W, n)
+    modes = {"none": L.RES_NONE, "after": L.RES_ADD_AFTER_ACT, "before": L.RES_ADD_BEFORE_ACT, "shuffle": L.RES_SHUFFLE2}
+    acts = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "silu": L.ACT_SILU}
+    pb.conv(xb.view(in_slice, k), w, ob.view(0, n), scale=scale, bias=bias, slope=slope if act == "prelu" else None,
+            act=acts[act], res=rb.view() if res_mode != "none" else None, res_mode=modes[res_mode])
+    plan = CompiledPlan(pb, dev)
+    assert plan.kernel_name(0).startswith("pwx6_kernel"), plan.kernel_name(0)
+    plan.buf_tensor(xb, N).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.buf_tensor(rb, N).copy_(torch.from_numpy(r).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(ob, N)
+    out_t.fill_(float("nan"))
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.permute(0, 3, 1, 2).cpu().numpy()
+    assert np.isfinite(got).all()
+
+    def ref(dt):
+        xs = torch.from_numpy(x[:, in_slice:in_slice + k]).to(dt)
+        v = F.conv2d(xs, torch.from_numpy(w).to(dt)) * torch.from_numpy(scale).to(dt).view(1, -1, 1, 1) + \
+            torch.from_numpy(bias).to(dt).view(1, -1, 1, 1)
+        rt = torch.from_numpy(r).to(dt)
+        if res_mode == "before":
+            v = v + rt
+        if act == "relu":
+            v = torch.relu(v)
+        elif act == "prelu":
+            v = torch.where(v > 0, v, v * torch.from_numpy(slope).to(dt).view(1, -1, 1, 1))
+        elif act == "silu":
+            v = v * torch.sigmoid(v)
+        if res_mode == "after":
+            v = v + rt
+        if res_mode == "shuffle":
+            v = torch.stack([rt, v], dim=2).reshape(N, 2 * n, H, W)
+        return v.numpy()
+    want, want64 = ref(torch.float32), ref(torch.float64)
+    assert rel_err(got, want) < 1e-5
+    tol = 2e-5 if act == "silu" else 1e-5       # fp_silu: hardware exp2 / rcp (~1e-6 relative, DESIGN numerics)
+    np.testing.assert_allclose(got, want, rtol=tol, atol=2e-5)
+    assert np.abs(got - want64).max() <= 2.0 * np.abs(want - want64).max() + (4e-6 if act == "silu" else 1e-6)
 
 
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
