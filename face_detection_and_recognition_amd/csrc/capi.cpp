@@ -82,7 +82,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
   if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3)) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV) return FP_ERR_INVALID_ARG;
-  if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !fp_pwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
     return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
@@ -131,7 +131,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.kind != FP_OP_BLAZEBLOCK) {
       const int64_t K = (int64_t)op.KH * op.KW * (op.kind == FP_OP_STEM_U8 ? 4 : op.Cin);
       wext = ((K + 7) / 8 * 8) * ((op.Cout + 31) / 32 * 32);
-      if (op.flags & FP_OPF_SPLIT3) wext = fp_pwx6_w_floats(op);   // three bf16 planes: 1.5 floats per weight
+      if (op.flags & FP_OPF_SPLIT3) wext = fp_convx6_w_floats(op);   // three bf16 planes: 1.5 floats per (padded) weight
     } else {
       // BLAZEBLOCK: dw weights [9][Cin] followed (separately addressed) by the packed 1x1; w_off addresses the
       // dw weights, scale_off the dw bias, slope_off the packed pointwise weights, bias_off the pointwise bias.
@@ -239,7 +239,8 @@ const char* fp_op_kernel_name(const fp_op* op) {
   switch (op->kind) {
     case FP_OP_CONV: {
       if (op->flags & FP_OPF_SPLIT3) {
-        snprintf(buf, sizeof(buf), "pwx6_kernel<%d>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8);
+        if (fp_pwx6_eligible(*op)) snprintf(buf, sizeof(buf), "pwx6_kernel<%d>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8);
+        else snprintf(buf, sizeof(buf), "convx6_kernel<%d>", fp_convx6_nt16(*op));
         return buf;
       }
       if (fp_pws_eligible(*op)) { snprintf(buf, sizeof(buf), "pws_kernel<%d, %d>", op->Cin, op->Cin == 64 ? 12 : 8); return buf; }

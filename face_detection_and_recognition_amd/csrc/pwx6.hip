@@ -180,6 +180,195 @@ int launch(const PwX6Args& a, hipStream_t s) {
   return FP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// convx6_kernel: the same scheme for dense 3x3 convs (pad 1, stride 1 / 2: YOLOv5-face's Bottleneck.cv2 and downsampling
+// Convs, y5/models/common.py:35-56,76-88) and for pointwise convs whose widths are not multiples of 32 / 16 (the in-tree
+// yolov5s widths 92, 184, 360).  Rows are OUTPUT pixels; the K loop runs over (tap, 32-channel slab); a lane's A fragment
+// for a slab is 8 consecutive channels of input pixel (oy*s + dy - pad, ox*s + dx - pad) -- two 16-byte loads straight from
+// global memory (the nine taps of a pixel hit L1 / L2), zero outside the image or beyond Cin -- split in registers as
+// above.  Weight slabs [tap * CS + cs][3][Npad][32] with zero rows / columns in the padding; outputs beyond Cout are not stored.
+struct ConvX6Args {
+  const float* in;
+  float* out;
+  const float* res;
+  const unsigned short* w;
+  const float* scale;
+  const float* bias;
+  const float* slope;
+  long M;
+  int H, W, OH, OW, Cin, Cout, Npad, KH, stride, pad;
+  int in_ld, out_ld, res_ld, res_C, act, res_mode;
+  long in_ns;
+  fp_divisor div_ohw, div_ow;
+};
+
+template <int NT16>
+__global__ __launch_bounds__(256, 2) void convx6_kernel(ConvX6Args p) {
+  constexpr int NC = NT16 * 16;
+  constexpr int SLAB = 3 * NC * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Bl = (unsigned short*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int nchunk = p.Npad / NC;
+  const int chunk = blockIdx.x % nchunk;
+  const long row0 = (long)(blockIdx.x / nchunk) * BM + wave * (MT * 16);
+  const int c0 = chunk * NC;
+  const int CS = (p.Cin + 31) / 32;
+  const int NSL = p.KH * p.KH * CS;                      // slabs: (tap, channel slab)
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int sl) {
+    unsigned char* dst = (unsigned char*)(Bl + (sl & 1) * SLAB);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned char* src = (const unsigned char*)(p.w + ((long)(sl * 3 + pl) * p.Npad + c0) * 32) + lane * 16;
+#pragma unroll
+      for (int j = 0; j < (NT16 + 3) / 4; ++j) {
+        const int c = j * 4 + wave;
+        if (c < NT16)
+          __builtin_amdgcn_global_load_lds((gbl_ptr)(src + c * 1024), (lds_ptr)(dst + (pl * NC * 32 + c * 512) * 2), 16, 0, 0);
+      }
+    }
+  };
+
+  // this lane's output pixels: tile t -> row row0 + 16 t + l15 -> (n, oy, ox); kept as the float offset of input pixel
+  // (oy*s - pad, ox*s - pad) of image n (may point outside the image: only dereferenced for valid taps) + iy0 / ix0
+  int nimg[MT], iyx[MT];   // image index; (iy0 << 16) | (ix0 & 0xffff) with iy0 / ix0 = oy*s - pad / ox*s - pad (two ints, not
+                           // a 64-bit address + two coordinates per tile: the 128-accumulator form has no registers to spare)
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    long r = row0 + 16 * t + l15;
+    r = r < p.M ? r : p.M - 1;
+    const unsigned n = fp_fastdiv((unsigned)r, p.div_ohw);
+    const unsigned rem = (unsigned)r - n * (unsigned)(p.OH * p.OW);
+    const unsigned oy = fp_fastdiv(rem, p.div_ow), ox = rem - oy * p.OW;
+    nimg[t] = (int)n;
+    iyx[t] = (((int)oy * p.stride - p.pad) << 16) | (((int)ox * p.stride - p.pad) & 0xffff);
+  }
+  f32x4 araw[MT][2];
+  auto load_a = [&](int sl) {
+    const int tap = sl / CS, cs = sl - tap * CS;
+    const int dy = tap / p.KH, dx = tap - dy * p.KH;
+    const int k0 = 32 * cs + 8 * q;
+    const bool k_lo = k0 < p.Cin, k_hi = k0 + 4 < p.Cin;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int iy = (iyx[t] >> 16) + dy, ix = (int)(short)(iyx[t] & 0xffff) + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const float* src = p.in + ((long)nimg[t] * p.in_ns + (long)((iy * p.W + ix) * p.in_ld + k0));
+      araw[t][0] = ok && k_lo ? *(const f32x4*)src : z;
+      araw[t][1] = ok && k_hi ? *(const f32x4*)(src + 4) : z;
+    }
+  };
+
+  f32x4 acc[MT][NT16];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) acc[t][n] = z;
+
+  stage(0);
+  load_a(0);
+  for (int sl = 0; sl < NSL; ++sl) {
+    fp_frag3 af[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) af[t] = fp_split8(araw[t][0], araw[t][1]);
+    __syncthreads();
+    if (sl + 1 < NSL) {
+      stage(sl + 1);
+      load_a(sl + 1);
+    }
+    const unsigned short* Bc = Bl + (sl & 1) * SLAB + (l15 * 32 + 8 * q);
+    fp_frag3 bf[2];
+    auto ldb = [&](int n, fp_frag3& b) {
+      b.h = *(const u32x4*)(Bc + n * 512);
+      b.m = *(const u32x4*)(Bc + NC * 32 + n * 512);
+      b.l = *(const u32x4*)(Bc + 2 * NC * 32 + n * 512);
+    };
+    ldb(0, bf[0]);
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) {
+      if (n + 1 < NT16) ldb(n + 1, bf[(n + 1) & 1]);
+      const fp_frag3& b = bf[n & 1];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][n] = fp_mfma_x6(b.h, b.m, b.l, af[t].h, af[t].m, af[t].l, acc[t][n]);
+    }
+  }
+
+  const bool shuffle = p.res_mode == FP_RES_SHUFFLE2;
+#pragma unroll
+  for (int n = 0; n < NT16; ++n) {
+    const int ch = c0 + 16 * n + 4 * q;
+    if (ch < p.Cout) {
+      const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+      const f32x4 sc = p.scale ? *(const f32x4*)(p.scale + ch) : one;
+      const f32x4 bi = p.bias ? *(const f32x4*)(p.bias + ch) : z;
+      const f32x4 sl = p.act == FP_ACT_PRELU ? *(const f32x4*)(p.slope + ch) : z;
+      f32x4 rv[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        long r = row0 + 16 * t + l15;
+        r = r < p.M ? r : p.M - 1;
+        rv[t] = z;
+        if (p.res_mode != FP_RES_NONE && ch < p.res_C) rv[t] = *(const f32x4*)(p.res + r * p.res_ld + ch);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const long r = row0 + 16 * t + l15;
+        f32x4 v = acc[t][n] * sc + bi;
+        if (p.res_mode == FP_RES_ADD_BEFORE_ACT) v += rv[t];
+        if (p.act == FP_ACT_RELU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        } else if (p.act == FP_ACT_PRELU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * sl[i];
+        } else if (p.act == FP_ACT_SILU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fp_silu(v[i]);
+        }
+        if (p.res_mode == FP_RES_ADD_AFTER_ACT) v += rv[t];
+        if (r < p.M) {
+          if (shuffle) {
+            float* o = p.out + r * p.out_ld + 2 * ch;
+            *(f32x4*)o = f32x4{rv[t][0], v[0], rv[t][1], v[1]};
+            *(f32x4*)(o + 4) = f32x4{rv[t][2], v[2], rv[t][3], v[3]};
+          } else {
+            *(f32x4*)(p.out + r * p.out_ld + ch) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NT16>
+int launch_conv(const ConvX6Args& a, hipStream_t s) {
+  constexpr int lds = 2 * 3 * NT16 * 16 * 32 * 2;
+  const long tiles = (a.M + BM - 1) / BM * (a.Npad / (NT16 * 16));
+  if (tiles >= (1L << 31)) return FP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((convx6_kernel<NT16>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+// column tiling of a general Cout: (16-column tiles per chunk, padded width)
+void general_tiles(int cout, int* nt16, int* npad) {
+  const int nt = (cout + 15) / 16;
+  int per;
+  if (nt <= 3) per = 3;
+  else if (nt <= 4) per = 4;
+  else if (nt <= 6) per = 6;
+  else {   // chunks of 6 or 4 tiles, whichever pads less (8-tile chunks leave convx6_kernel no registers for its addressing)
+    const int p6 = (nt + 5) / 6 * 6, p4 = (nt + 3) / 4 * 4;
+    per = p6 <= p4 ? 6 : 4;
+  }
+  *nt16 = per;
+  *npad = (nt + per - 1) / per * per * 16;
+}
+
 int chunk_tiles(int N) { return N == 48 ? 3 : N == 64 ? 4 : (N % 128 == 0 ? 8 : 0); }
 
 }  // namespace
@@ -229,5 +418,69 @@ int fp_launch_pwx6(const fp_op& op, const float* weights, float* arena, hipStrea
     case 3: return launch<3>(a, s);
     case 4: return launch<4>(a, s);
     default: return launch<8>(a, s);
+  }
+}
+
+// The general form (convx6_kernel): 3x3 pad 1 stride 1 / 2, or pointwise with widths that pwx6_kernel does not take.
+static bool convx6_shape(const fp_op& op) {
+  const bool k3 = op.KH == 3 && op.KW == 3 && op.pad_t == 1 && op.pad_l == 1 && (op.stride == 1 || op.stride == 2) &&
+                  op.OH == (op.H + 2 - 3) / op.stride + 1 && op.OW == (op.W + 2 - 3) / op.stride + 1;
+  const bool k1 = op.KH == 1 && op.KW == 1 && op.stride == 1 && !op.pad_t && !op.pad_l && op.OH == op.H && op.OW == op.W;
+  return k3 || k1;
+}
+
+bool fp_convx6_eligible(const fp_op& op) {
+  if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3) || (op.flags & ~FP_OPF_SPLIT3)) return false;
+  if (!convx6_shape(op) || op.Cin % 4 || op.Cin < 32 || op.Cout % 4 || op.Cout < 32 || op.out_cmul != 1) return false;
+  const long OHW = (long)op.OH * op.OW;
+  if (op.in_ns < (long)op.H * op.W * op.in_ld || op.out_ns != OHW * op.out_ld) return false;
+  if (op.in_ld % 4 || op.in_off % 4 || op.in_ns % 4 || op.out_ld % 4 || op.out_off % 4 || op.w_off % 4) return false;
+  if ((op.scale_off >= 0 && op.scale_off % 4) || (op.bias_off >= 0 && op.bias_off % 4) || (op.slope_off >= 0 && op.slope_off % 4)) return false;
+  if (op.act == FP_ACT_PRELU && op.slope_off < 0) return false;
+  if (op.res_mode != FP_RES_NONE) {
+    if (op.res_mode == FP_RES_POOL2_BEFORE_ACT) return false;
+    if (op.res_ns != OHW * op.res_ld || op.res_ld % 4 || op.res_off % 4 || op.res_C % 4) return false;
+    if (op.res_mode == FP_RES_SHUFFLE2 && (op.res_C < op.Cout || op.out_ld < 2 * op.Cout)) return false;
+  }
+  if ((long)op.N * OHW >= (1L << 31) || OHW < 2 || op.OW < 2) return false;   // 32-bit row decode by multiply-high (divisors >= 2)
+  return true;
+}
+
+int fp_convx6_nt16(const fp_op& op) {
+  int nt16, npad;
+  general_tiles(op.Cout, &nt16, &npad);
+  return nt16;
+}
+
+long fp_convx6_w_floats(const fp_op& op) {
+  int nt16, npad;
+  general_tiles(op.Cout, &nt16, &npad);
+  return (long)op.KH * op.KW * ((op.Cin + 31) / 32) * 3 * npad * 32 / 2;
+}
+
+int fp_launch_convx6(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  if (!fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
+  ConvX6Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = arena + op.in_off;
+  a.out = arena + op.out_off;
+  a.res = op.res_mode != FP_RES_NONE ? arena + op.res_off : nullptr;
+  a.w = (const unsigned short*)(weights + op.w_off);
+  a.scale = op.scale_off >= 0 ? weights + op.scale_off : nullptr;
+  a.bias = op.bias_off >= 0 ? weights + op.bias_off : nullptr;
+  a.slope = op.slope_off >= 0 ? weights + op.slope_off : nullptr;
+  a.M = (long)op.N * op.OH * op.OW;
+  a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.Cin = op.Cin; a.Cout = op.Cout;
+  a.KH = op.KH; a.stride = op.stride; a.pad = op.pad_t;
+  a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.res_ld = op.res_ld; a.res_C = op.res_C; a.act = op.act; a.res_mode = op.res_mode;
+  a.in_ns = op.in_ns;
+  a.div_ohw = fp_make_divisor((unsigned)(op.OH * op.OW));
+  a.div_ow = fp_make_divisor((unsigned)op.OW);
+  int nt16;
+  general_tiles(op.Cout, &nt16, &a.Npad);
+  switch (nt16) {
+    case 3: return launch_conv<3>(a, s);
+    case 4: return launch_conv<4>(a, s);
+    default: return launch_conv<6>(a, s);
   }
 }

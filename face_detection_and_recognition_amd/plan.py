@@ -258,19 +258,49 @@ class PlanBuilder:
     # kernels of rounds 1-3).  Mobile-FaceNet's Depth_Wise.X6 is this attribute.
     X6 = True
 
+    # Dense 3x3 convs (pad 1, stride 1 / 2) with at least this many input channels on the split-MFMA kernel as well
+    # (csrc/pwx6.hip convx6_kernel; widths padded to 32 / 16 inside the weight planes); 0 = never.
+    CONV3_X6_MIN_K = 48
+
+    @staticmethod
+    def x6_tiles(cout):
+        """(16-column tiles per chunk, padded width) -- mirror of general_tiles (csrc/pwx6.hip)."""
+        nt = (cout + 15) // 16
+        if nt <= 3:
+            per = 3
+        elif nt <= 4:
+            per = 4
+        elif nt <= 6:
+            per = 6
+        else:
+            p6, p4 = (nt + 5) // 6 * 6, (nt + 3) // 4 * 4
+            per = 6 if p6 <= p4 else 4
+        return per, (nt + per - 1) // per * per * 16
+
     @classmethod
     def pwx6_ok(cls, x, out, kh, kw, stride, pad, res, res_mode):
-        """Mirror of fp_pwx6_eligible (csrc/pwx6.hip) + the size policy above."""
-        if not cls.X6 or not cls.PW_X6_MIN_K or x.C < cls.PW_X6_MIN_K:
+        """Mirror of fp_pwx6_eligible / fp_convx6_eligible (csrc/pwx6.hip) + the size policy above."""
+        if not cls.X6 or out.cmul != 1 or x.buf.rowpad or out.buf.rowpad:
             return False
-        if (kh, kw, stride) != (1, 1, 1) or tuple(pad) != (0, 0) or (out.H, out.W) != (x.H, x.W):
+        k3 = (kh, kw) == (3, 3) and tuple(pad) == (1, 1) and stride in (1, 2) and \
+            (out.H, out.W) == ((x.H + 2 - 3) // stride + 1, (x.W + 2 - 3) // stride + 1)
+        k1 = (kh, kw, stride) == (1, 1, 1) and tuple(pad) == (0, 0) and (out.H, out.W) == (x.H, x.W)
+        if k1:
+            if not cls.PW_X6_MIN_K or x.C < cls.PW_X6_MIN_K:
+                return False
+        elif k3:
+            if not cls.CONV3_X6_MIN_K or x.C < cls.CONV3_X6_MIN_K:
+                return False
+        else:
             return False
-        if x.C % 32 or not (out.C in (48, 64) or out.C % 128 == 0) or out.cmul != 1 or x.buf.rowpad or out.buf.rowpad:
+        fast = k1 and x.C % 32 == 0 and (out.C in (48, 64) or out.C % 128 == 0) and x.buf.ns == x.H * x.W * x.buf.ld
+        if x.C % 4 or out.C % 4 or out.C < 32 or (not fast and (out.H * out.W < 2 or out.W < 2)):
             return False
-        hw = x.H * x.W
-        views = [x, out] + ([res] if res_mode != L.RES_NONE else [])
-        for v in views:
-            if v.buf.ns != hw * v.buf.ld or v.buf.ld % 4 or (v.buf.off + v.coff) % 4:
+        ohw = out.H * out.W
+        if x.buf.ns < x.H * x.W * x.buf.ld or x.buf.ns % 4 or x.buf.ld % 4 or (x.buf.off + x.coff) % 4:
+            return False
+        for v in [out] + ([res] if res_mode != L.RES_NONE else []):
+            if v.buf.ns != ohw * v.buf.ld or v.buf.ld % 4 or (v.buf.off + v.coff) % 4:
                 return False
         if res_mode == L.RES_POOL2_BEFORE_ACT:
             return False
@@ -292,10 +322,13 @@ class PlanBuilder:
         op.pad_t, op.pad_l = pad
         op.act, op.res_mode = act, res_mode
         if self.pwx6_ok(x, out, kh, kw, stride, pad, res, res_mode) and not op.flags:
-            # three bf16 planes [K / 32][3][N][32] (include/facepath.h, FP_OPF_SPLIT3 on FP_OP_CONV)
-            full = np.zeros((out.C, x.C), np.float32)
-            full[:cout, :cin] = np.asarray(w, np.float32).reshape(cout, cin)
-            w3 = split3_bf16(full).reshape(3, out.C, x.C // 32, 32).transpose(2, 0, 1, 3)
+            # three bf16 planes [tap * CS + cs][3][Npad][32] (include/facepath.h, FP_OPF_SPLIT3 on FP_OP_CONV): K runs
+            # over (tap, 32-channel slab), zero rows / columns in the padding of Cin to 32 and Cout to whole chunks
+            cs = (x.C + 31) // 32
+            npad = self.x6_tiles(out.C)[1]
+            full = np.zeros((kh * kw, npad, cs * 32), np.float32)
+            full[:, :cout, :cin] = np.asarray(w, np.float32).reshape(cout, cin, kh * kw).transpose(2, 0, 1)
+            w3 = split3_bf16(full).reshape(3, kh * kw, npad, cs, 32).transpose(1, 3, 0, 2, 4)
             op.w_off = self.add_weight(np.ascontiguousarray(w3).reshape(-1).view(np.float32))
             op.flags |= L.OPF_SPLIT3
         else:
