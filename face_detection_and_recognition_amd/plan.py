@@ -11,6 +11,8 @@ to multiples of 4 (16-byte accesses) with zero weights in the padding.
 import ctypes as C
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -252,15 +254,17 @@ class PlanBuilder:
         return op
 
     # Pointwise convs with K >= PW_X6_MIN_K input channels on the bf16x6 split-MFMA kernel (csrc/pwx6.hip); 0 = never.
-    # Below 128 channels the fp32-MFMA kernels already run at the HBM rate of these shapes.
-    PW_X6_MIN_K = 128
+    # (YOLOv5n-face forward at batch 256: 18.2 ms with 128, 17.0 ms with 64, 17.5 ms with 32.)
+    PW_X6_MIN_K = int(os.environ.get("FP_PW_X6_MIN_K", "64"))         # (the environment variables are lab knobs)
     # Master switch of the bf16x6 split-MFMA kernels (csrc/split.h): False = every GEMM on the fp32 MFMA (the fmaf-chain
     # kernels of rounds 1-3).  Mobile-FaceNet's Depth_Wise.X6 is this attribute.
     X6 = True
 
     # Dense 3x3 convs (pad 1, stride 1 / 2) with at least this many input channels on the split-MFMA kernel as well
     # (csrc/pwx6.hip convx6_kernel; widths padded to 32 / 16 inside the weight planes); 0 = never.
-    CONV3_X6_MIN_K = 48
+    CONV3_X6_MIN_K = int(os.environ.get("FP_CONV3_X6_MIN_K", "32"))
+    X6_SMALL_K_MIN_PIXELS = 400   # below 128 input channels only on maps of at least 20 x 20 (measured on YOLOv5-face; the
+                                  # small-map 1x1 convs of BlazeFace stay on the fp32-MFMA kernels)
 
     @staticmethod
     def x6_tiles(cout):
@@ -292,6 +296,8 @@ class PlanBuilder:
             if not cls.CONV3_X6_MIN_K or x.C < cls.CONV3_X6_MIN_K:
                 return False
         else:
+            return False
+        if x.C < 128 and out.H * out.W < cls.X6_SMALL_K_MIN_PIXELS:
             return False
         fast = k1 and x.C % 32 == 0 and (out.C in (48, 64) or out.C % 128 == 0) and x.buf.ns == x.H * x.W * x.buf.ld
         if x.C % 4 or out.C % 4 or out.C < 32 or (not fast and (out.H * out.W < 2 or out.W < 2)):

@@ -724,7 +724,7 @@ def test_pwx6_pointwise_conv_vs_torch(dev, k, n, act, res_mode, shape, in_slice)
     (128, 128, 3, 2, "silu", "none", (2, 40, 40)),     # downsampling Conv: two chunks of four column tiles
     (92, 92, 3, 1, "silu", "after", (2, 20, 24)),      # yolov5s width: Cin masked to 96, Cout padded to six tiles
     (184, 360, 3, 2, "silu", "none", (1, 21, 19)),     # odd map, 23 column tiles padded to 24, 6 channel slabs of which the last is partial
-    (48, 48, 3, 1, "relu", "none", (3, 17, 17)),       # smallest 3x3 the policy sends here
+    (48, 48, 3, 1, "relu", "none", (3, 21, 21)),       # a narrow 3x3 (K < 128: only on maps of >= 400 pixels)
     (184, 184, 1, 1, "silu", "none", (2, 20, 20)),     # pointwise with a width pwx6_kernel does not take
     (720, 360, 1, 1, "silu", "none", (1, 20, 20)),     # 23 K slabs (the last one half full)
     (360, 48, 1, 1, "none", "none", (2, 10, 10)),      # Detect head of yolov5s
@@ -1213,7 +1213,11 @@ def test_conv3_lds_image_kernel_vs_torch(dev, cin, cout, hw, stride, res, n):
     if res:
         assert stride == 1 and cin == cout
         kw.update(res=xv, res_mode=L.RES_ADD_AFTER_ACT)
-    pb.conv(xv, w, View(out, 8, cout), **kw)
+    PlanBuilder.X6 = False                                # the fp32-MFMA kernel is what this test is about
+    try:
+        pb.conv(xv, w, View(out, 8, cout), **kw)
+    finally:
+        PlanBuilder.X6 = True
     plan = CompiledPlan(pb, dev)
     assert plan.kernel_name(0).startswith("conv3_kernel"), plan.kernel_name(0)
     plan.arena.zero_()
