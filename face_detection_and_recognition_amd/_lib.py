@@ -22,6 +22,7 @@ ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
 RES_NONE, RES_ADD_BEFORE_ACT, RES_ADD_AFTER_ACT, RES_POOL2_BEFORE_ACT, RES_SHUFFLE2 = 0, 1, 2, 3, 4
 OPF_IN_ROWPAD, OPF_OUT_ROWPAD = 1, 2   # fp_op.flags: row-padded input / output view (include/facepath.h)
 OPF_IN_C3 = 4                          # 4-float pixel whose fourth channel meets zero weights
+OPF_IN_DW = 16                         # DWBLOCK: a depthwise Conv_block in front of the block, computed in its prologue
 OPF_SPLIT3 = 8                         # GEMM weights packed as three bf16 planes (bf16x6 split-MFMA kernels)
 
 

@@ -80,7 +80,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
-  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3)) return FP_ERR_INVALID_ARG;
+  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW)) return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_IN_DW) && (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3))) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
@@ -174,6 +175,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (!(x6 ? fp_dwblock_x6_supported(op) : fp_dwblock_supported(op))) return FP_ERR_UNSUPPORTED;
     if (!span_ok(op.w_off, x6 ? fp_dwblock_x6_we_floats(op) : (int64_t)op.Cin * op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
     if (!span_ok(op.scale_off, 15 * (int64_t)op.Cmid, weight_floats)) return FP_ERR_BOUNDS;
+    if ((op.flags & FP_OPF_IN_DW) && !span_ok(op.bias_off, 12 * (int64_t)op.Cin, weight_floats)) return FP_ERR_BOUNDS;
     if (!span_ok(op.slope_off, x6 ? fp_dwblock_x6_wp_floats(op) : (int64_t)op.Cmid * op.Cout + 2 * (int64_t)op.Cout, weight_floats))
       return FP_ERR_BOUNDS;
   }
@@ -293,7 +295,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       return buf;
     case FP_OP_DWBLOCK:
       if (op->flags & FP_OPF_SPLIT3) {
-        if (op->stride == 2) snprintf(buf, sizeof(buf), "dwblock_x6d_kernel<%d, %d, %d, %d>", op->Cin, op->Cmid, op->Cout, op->H);
+        if (op->stride == 2)
+          snprintf(buf, sizeof(buf), "dwblock_x6d_kernel<%d, %d, %d, %d, %s>", op->Cin, op->Cmid, op->Cout, op->H,
+                   (op->flags & FP_OPF_IN_DW) ? "true" : "false");
         else if (op->Cin == 128 && op->H == 7) snprintf(buf, sizeof(buf), "dwblock_x6q_kernel<%d>", op->H);
         else snprintf(buf, sizeof(buf), "dwblock_x6_kernel<%d, %d>", op->Cin, op->H);
         return buf;

@@ -46,6 +46,7 @@ struct DwbX6Args {
   const float* par;           // [15][G]: expand scale, bias, slope; 9 depthwise taps; depthwise scale, bias, slope
   const unsigned short* wp;   // project weights, split: [R][3][C co][32 g] bf16
   const float* paff;          // [C] project BN scale, [C] bias
+  const float* dwin;          // FP_OPF_IN_DW: [12][Cin] of the depthwise Conv_block in front: 9 taps, BN scale, BN bias, PReLU slope
   int N, has_res;
 #ifdef FP_X6_STAMPS
   unsigned long long* stamps;   // lab builds only (tools/lab/x6_lab.hip): s_memtime per phase, [block < 4][wave][round][8]
@@ -975,7 +976,12 @@ struct X6DCfg {
   static_assert(LDS_BYTES <= 80 * 1024 && MTE <= 4 * NOWN && (WL * 2) % 4096 == 0, "");
 };
 
-template <int CI, int G_, int CO, int HW>
+// DWIN: the block's input first passes through a depthwise 3x3 stride-1 Conv_block (+ BN + PReLU) -- Mobile-FaceNet's conv2_dw
+// in front of conv_23 (mobile_facenet.py:107-108,141-143).  It is computed in the prologue, one 32-channel slab at a time:
+// the band's rows of the tensor BEFORE conv2_dw (+ one halo row and column all around, zeros outside the image) go into an
+// LDS image by LDS-DMA, every lane forms the depthwise output of ITS fragment elements (pixel, 8 channels) from it and
+// splits it into the expand GEMM's operand -- the conv2_dw output (424 MB at 528 crops) is neither written nor read.
+template <int CI, int G_, int CO, int HW, bool DWIN>
 __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
   using K = X6DCfg<CI, G_, CO, HW>;
   constexpr int G = K::G, R = K::R, KS = K::KS;
@@ -1016,22 +1022,97 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
 
   // ---- prologue ----
   stage(0);
-  for (int i = tid; i < K::EB / 4; i += 256) *(f32x4*)&El[i * 4] = z;
   fp_frag3 xf[K::NOWN][KS];
   int eoff[K::NOWN];
+  if (DWIN) {
+    // S-image: rows elo - 1 .. ehi + 1 of the input (ER + 2 rows), row-padded like the E-image, 32 channels per slot; it
+    // overlays the E-image and D-tile regions (used only after this prologue)
+    constexpr int SROWS = K::ER + 2, SSLOT = SROWS * K::ROWP + 1;
+    static_assert(!DWIN || SSLOT * 32 * 4 <= K::EB * 4 + 3 * K::DPL * 2, "S-image overlays the E-image + D-tile");
+    float* Sl = El;
+    const int nrow = ehi - elo + 1;
+    // zeroed once: the DMA below only ever writes pixels inside the image, pads and outside rows stay zero for both slabs
+    for (int i = tid; i < (SSLOT * 32 + 3) / 4; i += 256) *(f32x4*)&Sl[i * 4] = z;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      __syncthreads();                                   // zero fill done / every lane is done reading the previous slab
+      // valid pixels: row vr of the S-image = input row elo - 1 + vr; 8 pixels (8 lanes x 16 B each) per wave instruction.
+      // The eight 16-byte units of a slot are XOR-swizzled by the slot index (the LDS-DMA writes lane * 16 contiguously, but
+      // WHICH global unit a lane fetches is free): 16 consecutive slots x one unit would otherwise sit in 2 bank groups.
+      for (int it = wave; it < (nrow + 2) * (HW / 8); it += 4) {
+        const int vr = it / (HW / 8), c8 = it - vr * (HW / 8);
+        const int row = elo - 1 + vr;
+        if (row >= 0 && row < HW) {                       // wave-uniform
+          const int slot0 = vr * K::ROWP + 8 * c8 + 1;
+          const int unit = (lane & 7) ^ ((slot0 + (lane >> 3)) & 7);
+          const float* src = xin + ((row * HW + 8 * c8 + (lane >> 3)) * CI + 32 * ks + 4 * unit);
+          __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Sl + slot0 * 32), 16, 0, 0);
+        }
+      }
+      __syncthreads();                                   // the DMA landed
+      // taps outermost: one tap's weights (8 registers) at a time, one accumulator pair per owned tile -- holding all nine
+      // taps' weights spilled 28 registers
+      const float* dp = p.dwin + 32 * ks + 8 * q;        // this lane's depthwise parameters: channels 32 ks + 8 q .. + 7
+      f32x4 a0[K::NOWN], a1[K::NOWN];
+      int s0[K::NOWN];
+#pragma unroll
+      for (int t = 0; t < K::NOWN; ++t) {
+        const int ec_ = min(16 * (wave + 4 * t) + l15, epx - 1);
+        const int er = ec_ / HW;
+        s0[t] = er * K::ROWP + (ec_ - er * HW);          // input pixel (elo + er + dy - 1, ecol + dx - 1) = S slot s0 + dy*ROWP + dx
+      }
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const f32x4 w0 = *(const f32x4*)(dp + t9 * CI), w1 = *(const f32x4*)(dp + t9 * CI + 4);
+#pragma unroll
+        for (int t = 0; t < K::NOWN; ++t) {
+          const int sl = s0[t] + (t9 / 3) * K::ROWP + (t9 % 3);
+          const float* sp = Sl + sl * 32;
+          const f32x4 v0 = *(const f32x4*)(sp + 4 * ((2 * q) ^ (sl & 7))), v1 = *(const f32x4*)(sp + 4 * ((2 * q + 1) ^ (sl & 7)));
+          if (t9 == 0) {
+            a0[t] = v0 * w0;
+            a1[t] = v1 * w1;
+          } else {
+            a0[t] += v0 * w0;
+            a1[t] += v1 * w1;
+          }
+        }
+      }
+      {
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+        const f32x4 sc0 = *(const f32x4*)(dp + 9 * CI), sc1 = *(const f32x4*)(dp + 9 * CI + 4);
+        const f32x4 bi0 = *(const f32x4*)(dp + 10 * CI), bi1 = *(const f32x4*)(dp + 10 * CI + 4);
+        const f32x4 sl0 = *(const f32x4*)(dp + 11 * CI) - one, sl1 = *(const f32x4*)(dp + 11 * CI + 4) - one;
+#pragma unroll
+        for (int t = 0; t < K::NOWN; ++t) {
+          f32x4 v0 = a0[t] * sc0 + bi0, v1 = a1[t] * sc1 + bi1, n0, n1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            n0[i] = __builtin_fminf(v0[i], 0.f);
+            n1[i] = __builtin_fminf(v1[i], 0.f);
+          }
+          xf[t][ks] = fp_split8(n0 * sl0 + v0, n1 * sl1 + v1);
+        }
+      }
+    }
+    __syncthreads();                                     // before the E-image region is zeroed
+  }
+  for (int i = tid; i < K::EB / 4; i += 256) *(f32x4*)&El[i * 4] = z;
 #pragma unroll
   for (int t = 0; t < K::NOWN; ++t) {
     const int e = 16 * (wave + 4 * t) + l15;
     const int ec_ = min(e, epx - 1);
-    const float* src = xin + (elo * HW + ec_) * CI + 8 * q;
-    f32x4 lo[KS], hi[KS];
+    if (!DWIN) {
+      const float* src = xin + (elo * HW + ec_) * CI + 8 * q;
+      f32x4 lo[KS], hi[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      lo[ks] = *(const f32x4*)(src + 32 * ks);
-      hi[ks] = *(const f32x4*)(src + 32 * ks + 4);
+      for (int ks = 0; ks < KS; ++ks) {
+        lo[ks] = *(const f32x4*)(src + 32 * ks);
+        hi[ks] = *(const f32x4*)(src + 32 * ks + 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[t][ks] = fp_split8(lo[ks], hi[ks]);
     }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[t][ks] = fp_split8(lo[ks], hi[ks]);
     const int er = ec_ / HW, ecol = ec_ - er * HW;
     const int slot = e < epx ? (vr0 + er) * K::ROWP + ecol + 1 : K::NSLOT;
     eoff[t] = slot * K::LDE + 4 * q;
@@ -1187,16 +1268,16 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
   }
 }
 
-template <int CI, int G_, int CO, int HW>
+template <int CI, int G_, int CO, int HW, bool DWIN = false>
 int launch_x6d(const DwbX6Args& a, hipStream_t s) {
   using K = X6DCfg<CI, G_, CO, HW>;
-  const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6d_kernel<CI, G_, CO, HW>,
+  const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6d_kernel<CI, G_, CO, HW, DWIN>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
     return FP_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((dwblock_x6d_kernel<CI, G_, CO, HW>), dim3(a.N * K::NBAND), dim3(256), K::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dwblock_x6d_kernel<CI, G_, CO, HW, DWIN>), dim3(a.N * K::NBAND), dim3(256), K::LDS_BYTES, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
@@ -1226,7 +1307,8 @@ bool fp_dwblock_x6_supported(const fp_op& op) {
   if (op.res_mode != FP_RES_NONE && op.res_mode != FP_RES_ADD_AFTER_ACT) return false;
   if (op.res_mode == FP_RES_ADD_AFTER_ACT &&
       (op.res_off != op.in_off || op.res_ns != op.in_ns || op.res_ld != op.in_ld || op.res_C != op.Cin)) return false;
-  if ((op.flags & ~FP_OPF_SPLIT3) || op.act2) return false;
+  if ((op.flags & ~(FP_OPF_SPLIT3 | FP_OPF_IN_DW)) || op.act2) return false;
+  if ((op.flags & FP_OPF_IN_DW) && !(op.stride == 2 && op.H == 56 && op.bias_off >= 0 && op.bias_off % 4 == 0)) return false;
   if ((long)op.N * (op.H / 7) * (op.H / 7) > 0x7fffffffL) return false;
   return true;
 }
@@ -1245,6 +1327,7 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   a.par = weights + op.scale_off;
   a.wp = (const unsigned short*)(weights + op.slope_off);
   a.paff = weights + op.slope_off + (long)op.Cmid * op.Cout * 3 / 2;
+  a.dwin = (op.flags & FP_OPF_IN_DW) ? weights + op.bias_off : nullptr;
   a.N = op.N;
   a.has_res = op.res_mode == FP_RES_ADD_AFTER_ACT;
   static const int stagger = getenv("FP_X6_STAGGER") ? atoi(getenv("FP_X6_STAGGER")) : 0;
@@ -1252,7 +1335,7 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
   static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
   if (op.stride == 2) {
-    if (op.H == 56) return launch_x6d<64, 128, 64, 56>(a, s);
+    if (op.H == 56) return (op.flags & FP_OPF_IN_DW) ? launch_x6d<64, 128, 64, 56, true>(a, s) : launch_x6d<64, 128, 64, 56>(a, s);
     return op.Cin == 64 ? launch_x6d<64, 256, 128, 28>(a, s) : launch_x6d<128, 512, 128, 14>(a, s);
   }
   if (op.Cin == 128 && op.H == 7) return launch_x6q<7>(a, s);

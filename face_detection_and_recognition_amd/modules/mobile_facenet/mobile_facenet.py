@@ -118,9 +118,10 @@ class Depth_Wise(_NoCompute, metaclass=_X6Switch):
             shapes.append(7)
         return tuple(shapes)
 
-    def emit(self, pb, x, expanded=None):
+    def emit(self, pb, x, expanded=None, in_dw=None):
         """expanded: the output of self.conv when the caller has already produced it (fused into the previous
-        depthwise Conv_block, see MobileFaceNet._emit); x is then only the residual source."""
+        depthwise Conv_block, see MobileFaceNet._emit); x is then only the residual source.  in_dw: a depthwise
+        Conv_block that precedes this block and is computed inside its kernel (FP_OPF_IN_DW: conv2_dw + conv_23)."""
         dw, pj, ex = self.conv_dw, self.project, self.conv
         shapes = Depth_Wise.BLOCK_SHAPES
         if shapes is None:
@@ -139,8 +140,10 @@ class Depth_Wise(_NoCompute, metaclass=_X6Switch):
             y = pb.new_buf(x.H // 2, x.W // 2, pj.out_c)
             pb.dwblock(x, npy(ex.conv.weight), _affine(ex.bn), npy(ex.prelu.weight),
                        npy(dw.conv.weight), _affine(dw.bn), npy(dw.prelu.weight),
-                       npy(pj.conv.weight), _affine(pj.bn), y.view(), False, split=True, stride=2)
+                       npy(pj.conv.weight), _affine(pj.bn), y.view(), False, split=True, stride=2,
+                       in_dw=None if in_dw is None else (npy(in_dw.conv.weight), _affine(in_dw.bn), npy(in_dw.prelu.weight)))
             return y
+        assert in_dw is None
         if (Depth_Wise.FUSE and expanded is None and x.H in shapes and dw.k == 3 and dw.p == 1 and
                 pb.dwblock_supported(x, ex.in_c, ex.out_c, pj.out_c, dw.s)):
             y = pb.new_buf(x.H, x.W, pj.out_c)
@@ -193,6 +196,7 @@ class MobileFaceNet(nn.Module):
 
     # conv2_dw + conv_23: True = depthwise launch + whole-block split-MFMA kernel; False = the round-2 pair of dw->pw kernels
     X6_CONV23 = True
+    X6_CONV2_IN = True    # ... with conv2_dw inside that kernel's prologue (False: a separate depthwise launch)
 
     def __init__(self, embedding_size):
         super().__init__()
@@ -236,10 +240,14 @@ class MobileFaceNet(nn.Module):
         if (Depth_Wise.FUSE and Depth_Wise.X6 and MobileFaceNet.X6_CONV23 and c23.conv_dw.s == 2 and not c23.residual and
                 x.H == x.W and c2.out_c == c23.conv.in_c and
                 (c23.conv.in_c, c23.conv.out_c, c23.project.out_c, x.H) in pb.DWBLOCK_X6D_SHAPES):
-            # conv2_dw as a plain depthwise launch, then ALL of conv_23 (expand -> dw stride 2 -> project) as one
-            # split-MFMA kernel: the 128-channel 56x56 tensor (848 MB at 528 crops) never exists
-            y = c2.emit(pb, x.view()); pb.free(x); x = y
-            y = c23.emit(pb, x.view()); pb.free(x); x = y
+            # conv2_dw + ALL of conv_23 (expand -> dw stride 2 -> project) as one split-MFMA kernel: conv2_dw is formed in
+            # the kernel's prologue from an LDS image of conv1's rows (FP_OPF_IN_DW); neither its output (424 MB at 528
+            # crops) nor the 128-channel 56x56 tensor (848 MB) ever exists
+            if MobileFaceNet.X6_CONV2_IN and c2.k == 3 and c2.s == 1 and c2.p == 1 and c2.groups == c2.in_c == c2.out_c:
+                y = c23.emit(pb, x.view(), in_dw=c2); pb.free(x); x = y
+            else:
+                y = c2.emit(pb, x.view()); pb.free(x); x = y
+                y = c23.emit(pb, x.view()); pb.free(x); x = y
         elif Depth_Wise.FUSE and c2.k == 3 and c2.s == 1 and c2.p == 1 and c2.groups % 64 == 0 and not c23.residual:
             # conv2_dw (dw3x3 + BN + PReLU) -> conv_23.conv (1x1 + BN + PReLU) as ONE dw->pw kernel: the 64-channel
             # 56x56 tensor between them (873 MB at N = 1088) never goes to HBM
@@ -288,7 +296,7 @@ class MobileFaceNet(nn.Module):
         shapes = Depth_Wise.BLOCK_SHAPES if Depth_Wise.BLOCK_SHAPES is not None else \
             Depth_Wise.block_policy(N if n_run is None else n_run)
         shapes = tuple(shapes)
-        return self._plans.get((N, shapes, Depth_Wise.FUSE, Depth_Wise.X6, MobileFaceNet.X6_CONV23), lambda cache: self._build(N, cache, block_shapes=shapes))
+        return self._plans.get((N, shapes, Depth_Wise.FUSE, Depth_Wise.X6, MobileFaceNet.X6_CONV23, MobileFaceNet.X6_CONV2_IN), lambda cache: self._build(N, cache, block_shapes=shapes))
 
     def forward(self, x):
         b = x.shape[0]

@@ -497,7 +497,8 @@ class PlanBuilder:
         return (stride == 2 and x.H == x.W and (cin, cmid, cout, x.H) in cls.DWBLOCK_X6D_SHAPES and x.coff == 0 and x.C == cin and
                 x.buf.ld == cin and x.buf.ns == x.H * x.W * cin and not x.buf.rowpad)
 
-    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual, split=False, stride=1):
+    def dwblock(self, x, e_w, e_aff, e_slope, dw_w, dw_aff, dw_slope, pw_w, pw_aff, out, residual, split=False, stride=1,
+                in_dw=None):
         """A whole Depth_Wise block (mobile_facenet.py:67-88) as ONE op (FP_OP_DWBLOCK, csrc/dwblock.hip): 1x1 expand
         + BN + PReLU -> dw3x3 (stride 1) + BN + PReLU -> 1x1 project + BN [+ x]; the expanded tensor stays in LDS.
         *_aff = (scale, bias) of the eval-mode BatchNorm."""
@@ -539,8 +540,18 @@ class PlanBuilder:
             op.res_C, op.res_H, op.res_W = cin, x.H, x.W
         self.ops.append(op)
         pix, opix = x.H * x.W, out.H * out.W
-        # the three convs of the block, each input once + output once
-        self.alg_bytes.append(4 * self.N * (pix * (cin + cmid) + (pix + opix) * cmid + opix * (cmid + cout)))
+        extra = 0
+        if in_dw is not None:
+            # OPF_IN_DW: a depthwise 3x3 stride-1 Conv_block (weights [C,1,3,3], (scale, bias), PReLU slope) in front of the
+            # block, computed in the kernel's prologue (conv2_dw + conv_23 of Mobile-FaceNet); parameters [12][Cin] at bias_off
+            iw, iaff, islope = in_dw
+            assert split and stride == 2 and (cin, cmid, cout, x.H) == (64, 128, 64, 56) and iw.shape == (cin, 1, 3, 3)
+            op.flags |= L.OPF_IN_DW
+            op.bias_off = self.add_weight(np.concatenate([pack_dw_weight(iw, cin), pad_vec(iaff[0], cin), pad_vec(iaff[1], cin),
+                                                          pad_vec(islope, cin)]))
+            extra = pix * 2 * cin
+        # the three convs of the block (+ the depthwise conv in front), each input once + output once
+        self.alg_bytes.append(4 * self.N * (extra + pix * (cin + cmid) + (pix + opix) * cmid + opix * (cmid + cout)))
         return out
 
     def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):

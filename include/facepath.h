@@ -156,6 +156,14 @@ typedef struct fp_op {
  *                "DWBLOCK".  The semantics of the op (mobile_facenet.py:67-88) do not change.
  */
 #define FP_OPF_SPLIT3 8
+/*
+ * FP_OPF_IN_DW (ABI 5) : an FP_OP_DWBLOCK whose input first passes through a depthwise 3x3 stride-1 Conv_block (conv + BN +
+ *                PReLU, mobile_facenet.py:39-51) -- Mobile-FaceNet's conv2_dw in front of conv_23 (:107-108,141-143).  bias_off
+ *                -> [12][Cin]: its nine taps (ky*3 + kx), BN scale, BN bias, PReLU slope.  Only with FP_OPF_SPLIT3 on the
+ *                (Cin 64, Cmid 128, Cout 64, 56 x 56, stride 2) block: the depthwise output is formed in the kernel's
+ *                prologue from an LDS image of the input rows and never goes to memory.
+ */
+#define FP_OPF_IN_DW 16
 
 /*
  * Weight blob layouts (packed by the host side, see

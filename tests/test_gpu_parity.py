@@ -775,6 +775,45 @@ def test_convx6_general_conv_vs_torch(dev, cin, cout, ks, stride, act, res_mode,
     assert np.abs(got - want64).max() <= 2.0 * np.abs(want - want64).max() + (2e-6 if act == "silu" else 2e-7) * np.abs(want64).max()
 
 
+@pytest.mark.parametrize("n", [3, 70, 530])
+def test_dwblock_x6_conv2_dw_in_front_vs_oracle(dev, n):
+    """FP_OPF_IN_DW: Mobile-FaceNet's conv2_dw (depthwise 3x3 + BN + PReLU, mobile_facenet.py:107,141) computed in the
+    prologue of conv_23's split-MFMA kernel, against the oracle's two blocks in sequence; image borders (zero padding of
+    BOTH depthwise convs), first / interior / last bands."""
+    from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Conv_block
+    rng = np.random.default_rng(5000 + n)
+    c2 = Conv_block(64, 64, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=64)
+    c2.load_state_dict(synth_state_dict(c2.state_dict(), 1400))
+    blk = Depth_Wise(64, 64, residual=False, kernel=(3, 3), stride=(2, 2), padding=(1, 1), groups=128)
+    sd = synth_state_dict(blk.state_dict(), 1401)
+    blk.load_state_dict(sd)
+    x = rng.normal(0, 1, (n, 64, 56, 56)).astype(np.float32)
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(56, 56, 64)
+    y = blk.emit(pb, inp.view(), in_dw=c2)
+    plan = CompiledPlan(pb, dev)
+    assert plan.n_ops == 1 and plan.kernel_name(0) == "dwblock_x6d_kernel<64, 128, 64, 56, true>", plan.kernel_name(0)
+    t = plan.buf_tensor(inp, n)
+    t.copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(y, n)
+    out_t.fill_(float("nan"))
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.permute(0, 3, 1, 2).cpu().numpy()
+
+    def ref(dt):
+        s2 = {k: torch.as_tensor(v).to(dt) if torch.as_tensor(v).is_floating_point() else torch.as_tensor(v) for k, v in c2.state_dict().items()}
+        s3 = {k: torch.as_tensor(v).to(dt) if torch.as_tensor(v).is_floating_point() else torch.as_tensor(v) for k, v in sd.items()}
+        h = mobilefacenet_ref._conv_block(s2, "", torch.from_numpy(x).to(dt), 1, 1, 64)
+        return mobilefacenet_ref._depth_wise(s3, "", h, 2, False).numpy()
+    want, want64 = ref(torch.float32), ref(torch.float64)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert rel_err(got, want) < 1e-5
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-5)
+    assert np.abs(got - want64).max() <= 2.0 * np.abs(want - want64).max() + 2e-7 * np.abs(want64).max()
+    np.testing.assert_array_equal(t.permute(0, 3, 1, 2).cpu().numpy(), x)
+
+
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
     """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through three plans (batch
     capacity 64, run on the golden's 4 images): (a) the default -- all twelve stride-1 blocks as the
