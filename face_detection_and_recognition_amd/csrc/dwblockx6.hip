@@ -51,7 +51,6 @@ struct DwbX6Args {
 #ifdef FP_X6_STAMPS
   unsigned long long* stamps;   // lab builds only (tools/lab/x6_lab.hip): s_memtime per phase, [block < 4][wave][round][8]
 #endif
-  int stagger;   // lab knob (FP_X6_STAGGER): units of 1024 cycles the second workgroup of a CU waits before its first round
 };
 
 #ifdef FP_X6_STAMPS
@@ -310,8 +309,6 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
   // workgroup barrier that waits for this wave's LDS traffic only: an LDS-DMA (vmcnt) may stay in flight across it
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  if (p.stagger > 0 && (__builtin_amdgcn_s_getreg(0x1804) & 1))   // HW_ID.WAVE_ID: odd wave slot = second workgroup of the CU
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   __syncthreads();   // E-image zeroed, round 0 staged (the barrier drains the LDS-DMA)
 
   for (int s = 0; s < R; ++s) {
@@ -1330,8 +1327,6 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   a.dwin = (op.flags & FP_OPF_IN_DW) ? weights + op.bias_off : nullptr;
   a.N = op.N;
   a.has_res = op.res_mode == FP_RES_ADD_AFTER_ACT;
-  static const int stagger = getenv("FP_X6_STAGGER") ? atoi(getenv("FP_X6_STAGGER")) : 0;
-  a.stagger = stagger;
   // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
   static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
   if (op.stride == 2) {

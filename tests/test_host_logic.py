@@ -235,3 +235,51 @@ def test_fused_letterbox_plans_validate_on_host(lib):
     assert lib.fp_letterbox_tables(576, 1024, 640, 640, 0, 0, 2048, 576, 0, 140, 640, 360, 125, 1, buf, None) != 0
     assert lib.fp_letterbox_tables(576, 1024, 640, 640, 0, 0, 1024, 576, 0, 140, 640, 700, 125, 1, buf, None) != 0
     assert lib.fp_letterbox_tables(70000, 1024, 640, 640, 0, 0, 1024, 70000, 0, 0, 640, 640, 125, 1, buf, None) != 0
+
+
+def test_split3_plan_layouts_and_validation():
+    """FP_OPF_SPLIT3 on the host: the weight planes PlanBuilder packs for the split-MFMA ops rebuild the fp32 weights
+    exactly in the layouts include/facepath.h documents, every network plan validates with the split kernels on and off,
+    and the switch changes which ops carry the flag."""
+    import numpy as np
+    from face_detection_and_recognition_amd import _lib as L
+    from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise, MobileFaceNet
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model
+    from face_detection_and_recognition_amd.plan import PlanBuilder, validate_on_host
+
+    def planes_to_f32(u16):
+        return (u16.astype(np.uint32) << 16).view(np.float32)
+
+    # pointwise conv: [K / 32][3][Npad][32]
+    rng = np.random.default_rng(0)
+    w = rng.normal(0, 1, (92, 184, 1, 1)).astype(np.float32)
+    pb = PlanBuilder(2)
+    x, o = pb.new_buf(24, 24, 184), pb.new_buf(24, 24, 92)
+    pb.conv(x.view(), w, o.view())
+    op = pb.ops[0]
+    assert op.flags & L.OPF_SPLIT3
+    per, npad = PlanBuilder.x6_tiles(92)
+    assert (per, npad) == (6, 96)
+    cs = (184 + 31) // 32
+    blob = np.concatenate(pb.wchunks)[op.w_off: op.w_off + cs * 3 * npad * 32 // 2].view(np.uint16).reshape(cs, 3, npad, 32)
+    full = planes_to_f32(blob).sum(axis=1, dtype=np.float64).astype(np.float32)      # h + m + l, exact in fp64 -> fp32
+    full = full.transpose(1, 0, 2).reshape(npad, cs * 32)
+    np.testing.assert_array_equal(full[:92, :184], w.reshape(92, 184))
+    assert not full[92:].any() and not full[:, 184:].any()                           # zero padding rows / columns
+    assert validate_on_host(pb) == 0
+
+    # every network, split kernels on / off
+    nets = [MobileFaceNet(512), Model("yolov5n").fuse(), Model("yolov5s").fuse()]
+    counts = {}
+    for flag in (True, False):
+        Depth_Wise.X6 = flag
+        try:
+            for net in nets:
+                pbn = net._emit(4)[0]
+                assert validate_on_host(pbn) == 0
+                counts[(type(net).__name__, getattr(net, "name", ""), flag)] = sum(1 for q in pbn.ops if q.flags & L.OPF_SPLIT3)
+        finally:
+            Depth_Wise.X6 = True
+    assert all(v == 0 for k, v in counts.items() if not k[2])
+    assert counts[("MobileFaceNet", "", True)] == 17          # 15 Depth_Wise blocks + conv_6_sep + the Linear
+    assert all(v > 0 for k, v in counts.items() if k[2])
