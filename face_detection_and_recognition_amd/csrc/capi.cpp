@@ -241,7 +241,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
   switch (op->kind) {
     case FP_OP_CONV: {
       if (op->flags & FP_OPF_SPLIT3) {
-        if (fp_pwx6_eligible(*op)) snprintf(buf, sizeof(buf), "pwx6_kernel<%d>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8);
+        if (fp_pwx6_eligible(*op)) snprintf(buf, sizeof(buf), "pwx6_kernel<%d, %d>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8, fp_pwx6_mt(*op));
         else snprintf(buf, sizeof(buf), "convx6_kernel<%d>", fp_convx6_nt16(*op));
         return buf;
       }

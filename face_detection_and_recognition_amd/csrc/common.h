@@ -92,6 +92,7 @@ long fp_dwblock_x6_wp_floats(const fp_op& op);
 int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pwx6_eligible(const fp_op& op);     // CONV with FP_OPF_SPLIT3: pointwise conv on the bf16x6 split-MFMA kernel (pwx6.hip)
 long fp_pwx6_w_floats(const fp_op& op);
+int fp_pwx6_mt(const fp_op& op);
 bool fp_convx6_eligible(const fp_op& op);   // ... the general form: 3x3 pad 1 stride 1 / 2, widths padded to 32 / 16 (convx6_kernel)
 long fp_convx6_w_floats(const fp_op& op);
 int fp_convx6_nt16(const fp_op& op);

@@ -35,12 +35,15 @@ struct PwX6Args {
   int K, N, in_ld, out_ld, res_ld, res_C, act, res_mode;
 };
 
-constexpr int MT = 4;        // 16-row tiles per wave
+constexpr int MT = 4;        // 16-row tiles per wave (convx6_kernel; pwx6_kernel's default)
 constexpr int BM = 4 * MT * 16;
 
-// NT16 = 16-column tiles of a column chunk (3: N = 48, 4: N = 64, 8: chunks of 128)
-template <int NT16>
-__global__ __launch_bounds__(256, 2) void pwx6_kernel(PwX6Args p) {
+// NT16 = 16-column tiles of a column chunk (3: N = 48, 4: N = 64, 8: chunks of 128); MT_ = 16-row tiles per wave: 4 (256-row
+// workgroup tiles, two workgroups per CU) or 2 (128-row tiles, three per CU) -- the launcher takes the small form when the
+// large one would leave the last round of workgroups mostly empty (409 600 rows = 1600 large tiles on 512 slots = 3.1 rounds)
+template <int NT16, int MT_>
+__global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p) {
+  constexpr int MT = MT_, BM = 4 * MT_ * 16;
   constexpr int NC = NT16 * 16;
   constexpr int SLAB = 3 * NC * 32;                      // bf16 elements of a weight slab
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -78,12 +81,15 @@ __global__ __launch_bounds__(256, 2) void pwx6_kernel(PwX6Args p) {
     r = r < p.M ? r : p.M - 1;
     arow[t] = p.in + r * p.in_ld + 8 * q;
   }
-  f32x4 araw[MT][2];
-  auto load_a = [&](int ks) {
+  // A slabs in flight: one ahead (large tiles: no registers for more) or two ahead (small tiles: a slab's MFMAs, 0.85 us, do not
+  // cover an HBM round trip).  The slab loop is written out for two buffers so that the register arrays are indexed statically.
+  constexpr int AD = MT == 2 ? 2 : 1;
+  f32x4 araw[AD][MT][2];
+  auto load_a = [&](int ks, int buf) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      araw[t][0] = *(const f32x4*)(arow[t] + 32 * ks);
-      araw[t][1] = *(const f32x4*)(arow[t] + 32 * ks + 4);
+      araw[buf][t][0] = *(const f32x4*)(arow[t] + 32 * ks);
+      araw[buf][t][1] = *(const f32x4*)(arow[t] + 32 * ks + 4);
     }
   };
 
@@ -93,16 +99,19 @@ __global__ __launch_bounds__(256, 2) void pwx6_kernel(PwX6Args p) {
 #pragma unroll
     for (int n = 0; n < NT16; ++n) acc[t][n] = z;
 
-  stage(0);
-  load_a(0);
-  for (int ks = 0; ks < KS; ++ks) {
+  auto slab = [&](int ks, int buf) {
     fp_frag3 af[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) af[t] = fp_split8(araw[t][0], araw[t][1]);
+    for (int t = 0; t < MT; ++t) af[t] = fp_split8(araw[buf][t][0], araw[buf][t][1]);
     __syncthreads();   // slab ks landed (own DMA waited for, then everybody's); every wave is done with slab ks - 1
-    if (ks + 1 < KS) {
-      stage(ks + 1);
-      load_a(ks + 1);
+    if (AD == 1) {
+      if (ks + 1 < KS) {
+        stage(ks + 1);
+        load_a(ks + 1, 0);
+      }
+    } else {
+      if (ks + 1 < KS) stage(ks + 1);
+      if (ks + AD < KS) load_a(ks + AD, buf);
     }
     const unsigned short* Bc = Bl + (ks & 1) * SLAB + (l15 * 32 + 8 * q);
     fp_frag3 bf[2];
@@ -118,6 +127,43 @@ __global__ __launch_bounds__(256, 2) void pwx6_kernel(PwX6Args p) {
       const fp_frag3& b = bf[n & 1];
 #pragma unroll
       for (int t = 0; t < MT; ++t) acc[t][n] = fp_mfma_x6(b.h, b.m, b.l, af[t].h, af[t].m, af[t].l, acc[t][n]);
+    }
+  };
+
+  stage(0);
+  load_a(0, 0);
+  if constexpr (AD == 2) {
+    if (KS > 1) load_a(1, 1);
+    for (int ks = 0; ks < KS; ks += 2) {
+      slab(ks, 0);
+      if (ks + 1 < KS) slab(ks + 1, 1);
+    }
+  } else {
+    // (the same slab step written in line: through the lambda above hipcc allocates five registers more and spills them)
+    for (int ks = 0; ks < KS; ++ks) {
+      fp_frag3 af[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[t] = fp_split8(araw[0][t][0], araw[0][t][1]);
+      __syncthreads();
+      if (ks + 1 < KS) {
+        stage(ks + 1);
+        load_a(ks + 1, 0);
+      }
+      const unsigned short* Bc = Bl + (ks & 1) * SLAB + (l15 * 32 + 8 * q);
+      fp_frag3 bf[2];
+      auto ldb = [&](int n, fp_frag3& b) {
+        b.h = *(const u32x4*)(Bc + n * 512);
+        b.m = *(const u32x4*)(Bc + NC * 32 + n * 512);
+        b.l = *(const u32x4*)(Bc + 2 * NC * 32 + n * 512);
+      };
+      ldb(0, bf[0]);
+#pragma unroll
+      for (int n = 0; n < NT16; ++n) {
+        if (n + 1 < NT16) ldb(n + 1, bf[(n + 1) & 1]);
+        const fp_frag3& b = bf[n & 1];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][n] = fp_mfma_x6(b.h, b.m, b.l, af[t].h, af[t].m, af[t].l, acc[t][n]);
+      }
     }
   }
 
@@ -170,12 +216,25 @@ __global__ __launch_bounds__(256, 2) void pwx6_kernel(PwX6Args p) {
   }
 }
 
+// rounds of workgroups the large tiles need (512 slots): below 8, and with a last round less than 70 % full -> small tiles
+bool pwx6_small_tiles(long M, int nchunk) {
+  const double rounds = (double)((M + BM - 1) / BM * nchunk) / 512.0;
+  const double frac = rounds - (double)(long)rounds;
+  return rounds < 8.0 && frac > 0.0 && frac < 0.7;
+}
+
 template <int NT16>
 int launch(const PwX6Args& a, hipStream_t s) {
   constexpr int lds = 2 * 3 * NT16 * 16 * 32 * 2;
-  const long tiles = (a.M + BM - 1) / BM * (a.N / (NT16 * 16));
-  if (tiles >= (1L << 31)) return FP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((pwx6_kernel<NT16>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+  const long nchunk = a.N / (NT16 * 16);
+  const long big = (a.M + BM - 1) / BM * nchunk;
+  if (2 * big >= (1L << 31)) return FP_ERR_UNSUPPORTED;
+  if (pwx6_small_tiles(a.M, (int)nchunk)) {
+    const long tiles = (a.M + BM / 2 - 1) / (BM / 2) * nchunk;
+    hipLaunchKernelGGL((pwx6_kernel<NT16, 2>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((pwx6_kernel<NT16, 4>), dim3((unsigned)big), dim3(256), lds, s, a);
+  }
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
@@ -393,6 +452,12 @@ bool fp_pwx6_eligible(const fp_op& op) {
 }
 
 long fp_pwx6_w_floats(const fp_op& op) { return (long)op.Cin * op.Cout * 3 / 2; }
+
+// 16-row tiles per wave the launcher will pick for this op at its current batch (kernel-name reporting)
+int fp_pwx6_mt(const fp_op& op) {
+  const int nt = chunk_tiles(op.Cout);
+  return nt && pwx6_small_tiles((long)op.N * op.H * op.W, op.Cout / (nt * 16)) ? 2 : 4;
+}
 
 int fp_launch_pwx6(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
   if (!fp_pwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
