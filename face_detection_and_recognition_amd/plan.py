@@ -300,7 +300,7 @@ class PlanBuilder:
         if x.C < 128 and out.H * out.W < cls.X6_SMALL_K_MIN_PIXELS:
             return False
         fast = k1 and x.C % 32 == 0 and (out.C in (48, 64) or out.C % 128 == 0) and x.buf.ns == x.H * x.W * x.buf.ld
-        if x.C % 4 or out.C % 4 or out.C < 32 or (not fast and (out.H * out.W < 2 or out.W < 2)):
+        if x.C % 4 or out.C % 4 or out.C < 48 or (not fast and (out.H * out.W < 2 or out.W < 2)):   # (32 outputs: a third of the three-tile chunk would be padding)
             return False
         ohw = out.H * out.W
         if x.buf.ns < x.H * x.W * x.buf.ld or x.buf.ns % 4 or x.buf.ld % 4 or (x.buf.off + x.coff) % 4:
