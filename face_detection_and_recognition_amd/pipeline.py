@@ -30,7 +30,7 @@ class FacePipeline:
     """detector: a BlazeFaceModel or YOLOV5FaceModel (HIP); embedder: a HIP MobileFaceNet;
     reference: (Nr, E) CUDA tensor of reference embeddings for the cosine filter (or None)."""
 
-    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=8):
+    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=8, two_streams=False):
         self.det = detector
         self.emb = embedder
         self.tau = float(tau)
@@ -38,6 +38,10 @@ class FacePipeline:
         self.bucket = int(bucket)
         self.dev = embedder._device()
         self.lut = mfn_lut(self.dev)
+        # step_overlapped with two_streams: embed + filter of batch k run on a SIDE stream beside the detector of batch
+        # k + 1 (the split-MFMA embedder kernels are matrix-core bound, the BlazeFace kernels vector-ALU / HBM bound, and
+        # every kernel's last, partly empty round of workgroups is filled by the other stream's work)
+        self.emb_stream = torch.cuda.Stream(device=self.dev) if two_streams else None
         self.set_reference(reference)
 
     def set_reference(self, reference):
@@ -131,9 +135,24 @@ class FacePipeline:
         cap = items.shape[0]
         if n > cap:
             raise L.FacepathError(f"{n} faces in the batch exceed max_faces_per_frame*B = {cap}")
-        emb = self.embed(frames, items, n)
-        res = self.filter(emb)
-        out = dict(n_faces=n, info=info[:n], emb=emb.clone(), items=items[:n])
+        if self.emb_stream is None:
+            emb = self.embed(frames, items, n)
+            res = self.filter(emb)
+            out = dict(n_faces=n, info=info[:n], emb=emb.clone(), items=items[:n])
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            self.emb_stream.wait_event(ev)                 # the crops of this batch (detector stream)
+            if getattr(self, "_emb_done", None) is not None:
+                main.wait_event(self._emb_done)            # (results of the batch before are complete for the caller)
+            with torch.cuda.stream(self.emb_stream):
+                for t in (frames, items, info):
+                    t.record_stream(self.emb_stream)
+                emb = self.embed(frames, items, n)
+                res = self.filter(emb)
+                out = dict(n_faces=n, info=info[:n], emb=emb.clone(), items=items[:n])
+                self._emb_done = torch.cuda.Event()
+                self._emb_done.record(self.emb_stream)
+            out["done"] = self._emb_done                   # the caller waits for this event before it reads the results
         if res is not None:
             out.update(best=res[0], arg=res[1], keep=res[2])
         return out

@@ -135,21 +135,26 @@ def test_blank_frames_give_empty_results_everywhere(dev):
     assert ypipe.step(torch.from_numpy(blank).to(dev))["n_faces"] == 0
 
 
-def test_pipeline_step_overlapped_equals_step(dev):
-    """FacePipeline.step_overlapped (the detector of batch k + 1 enqueued before the host reads batch k's face count)
-    returns, one call late, exactly what step() returns for the same batches; flush() hands out the last one."""
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_pipeline_step_overlapped_equals_step(dev, two_streams):
+    """FacePipeline.step_overlapped (the detector of batch k + 1 enqueued before the host reads batch k's face count; with
+    two_streams: embed + filter of batch k on a side stream beside it) returns, one call late, exactly what step() returns
+    for the same batches; flush() hands out the last one.  Five batches, so that the side stream really runs beside the
+    next detector pass and the embedder arena is reused while results of earlier batches are still held."""
     from face_detection_and_recognition_amd.pipeline import FacePipeline
     det = W.build_detector(dev, W.make_frames(8, dev, seed=8), cand_per_frame=48)
     emb = W.build_embedder(dev)
     ref = W.make_reference(300, dev)
-    pipe = FacePipeline(det, emb, ref, tau=0.1)
-    batches = [W.make_frames(6, dev, seed=40 + i) for i in range(3)]
+    pipe = FacePipeline(det, emb, ref, tau=0.1, two_streams=two_streams)
+    batches = [W.make_frames(6, dev, seed=40 + i) for i in range(5)]
     want = [pipe.step(b) for b in batches]
     got = [pipe.step_overlapped(b) for b in batches]
     assert got[0] is None
     got = got[1:] + [pipe.flush()]
     assert pipe.flush() is None
+    torch.cuda.synchronize()
     for a, b in zip(want, got):
+        assert ("done" in b) == two_streams
         assert a["n_faces"] == b["n_faces"] > 0
         for k in ("emb", "info", "items", "best", "arg", "keep"):
             assert torch.equal(a[k], b[k]), k
