@@ -814,6 +814,35 @@ def test_dwblock_x6_conv2_dw_in_front_vs_oracle(dev, n):
     np.testing.assert_array_equal(t.permute(0, 3, 1, 2).cpu().numpy(), x)
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3])
+def test_split_kernels_keep_fp32_dynamic_range(dev, scale):
+    """The three bf16 pieces carry fp32's exponent range, so the split kernels must be scale-invariant like an fp32 conv:
+    a pointwise conv (pwx6_kernel) on inputs of magnitude `scale` with a few exact powers of two, signed zeros and values
+    16 orders of magnitude apart in one row, against torch's fp32 result RELATIVE to the output scale (1e-5) and against
+    fp64 (not above twice the fp32 error)."""
+    rng = np.random.default_rng(17)
+    N, H, W, k, n = 2, 20, 20, 128, 128
+    x = (rng.normal(0, 1, (N, k, H, W)) * scale).astype(np.float32)
+    x[:, 0] = scale * 2.0 ** rng.integers(-20, 20, (N, H, W))          # exact powers of two
+    x[:, 1] = np.where(rng.random((N, H, W)) < 0.5, 0.0, -0.0)        # signed zeros
+    x[:, 2] = scale * 1e-16 * rng.normal(0, 1, (N, H, W))             # far below the row's scale
+    w = rng.normal(0, (2.0 / k) ** 0.5, (n, k, 1, 1)).astype(np.float32)
+    pb = PlanBuilder(N)
+    xb, ob = pb.new_buf(H, W, k), pb.new_buf(H, W, n)
+    pb.conv(xb.view(), w, ob.view())
+    plan = CompiledPlan(pb, dev)
+    assert plan.kernel_name(0).startswith("pwx6_kernel")
+    plan.buf_tensor(xb, N).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    got = plan.buf_tensor(ob, N).permute(0, 3, 1, 2).cpu().numpy()
+    want = F.conv2d(torch.from_numpy(x), torch.from_numpy(w)).numpy()
+    want64 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double()).numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < 1e-5
+    assert np.abs(got - want64).max() <= 2.0 * np.abs(want - want64).max() + 2e-7 * np.abs(want64).max()
+
+
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
     """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through three plans (batch
     capacity 64, run on the golden's 4 images): (a) the default -- all twelve stride-1 blocks as the
