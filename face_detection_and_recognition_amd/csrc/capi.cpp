@@ -82,7 +82,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
   if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW)) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_IN_DW) && (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3))) return FP_ERR_INVALID_ARG;
-  if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV) return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW) return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_DWPW && !fp_dwpwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
     return FP_ERR_INVALID_ARG;
@@ -150,7 +151,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.kind == FP_OP_DWPW) {
     // w_off: [9*G taps][G scale][G bias][G slope]; slope_off: [Kpad*Npad packed 1x1][Cout4 scale][Cout4 bias]
     if (!span_ok(op.w_off, 12 * (int64_t)op.Cin, weight_floats)) return FP_ERR_BOUNDS;
-    const int64_t pw = ((op.Cin + 7) / 8 * 8) * (int64_t)((op.Cout + 31) / 32 * 32) + 2 * (int64_t)((op.Cout + 3) / 4 * 4);
+    const int64_t pw = (op.flags & FP_OPF_SPLIT3) ? fp_dwpwx6_w_floats(op) :
+        ((op.Cin + 7) / 8 * 8) * (int64_t)((op.Cout + 31) / 32 * 32) + 2 * (int64_t)((op.Cout + 3) / 4 * 4);
     if (!span_ok(op.slope_off, pw, weight_floats)) return FP_ERR_BOUNDS;
     if (op.act != FP_ACT_NONE && op.act != FP_ACT_PRELU) return FP_ERR_INVALID_ARG;
     // bias_off: optional [Cout4] PReLU slopes of the projection output
@@ -282,6 +284,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
         snprintf(buf, sizeof(buf), "blazeblock_kernel<%d>", (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
     case FP_OP_DWPW:
+      if (op->flags & FP_OPF_SPLIT3) { snprintf(buf, sizeof(buf), "dwpwx6_kernel<%d, 4, %d>", op->Cout / 16, op->stride); return buf; }
       if (fp_dwpw_persistent(*op)) {
         snprintf(buf, sizeof(buf), fp_dwpw_wave_private(*op) ? "dwpw_wp_kernel<%d, %d, 4>" : "dwpw_persist_kernel<%d, %d>",
                  (int)fp_round_up(op->Cout, 32) / 32, op->stride);
@@ -334,7 +337,8 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_COPY: return fp_launch_copy(op, arena, s);
     case FP_OP_L2NORM: return fp_launch_l2norm(op, arena, s);
     case FP_OP_BLAZEBLOCK: return fp_launch_blazeblock(op, weights, arena, s);
-    case FP_OP_DWPW: return fp_launch_dwpw(op, weights, arena, s);
+    case FP_OP_DWPW:
+      return (op.flags & FP_OPF_SPLIT3) ? fp_launch_dwpwx6(op, weights, arena, s) : fp_launch_dwpw(op, weights, arena, s);
     case FP_OP_DWBLOCK:
       return (op.flags & FP_OPF_SPLIT3) ? fp_launch_dwblock_x6(op, weights, arena, s) : fp_launch_dwblock(op, weights, arena, s);
     case FP_OP_BLAZEPAIR: return fp_launch_blazepair(op, weights, arena, s);

@@ -79,6 +79,9 @@ bool fp_blazeblock_wps_eligible(const fp_op& op);  // ... its small-map form for
 int fp_launch_blazeblock_rowpad(const fp_op& op, const float* weights, float* arena, hipStream_t s);   // blazewp.hip
 bool fp_blazeblock_fixed24(const fp_op& op);   // persistent BlazeBlock instantiated with compile-time 24 -> 24 widths
 int fp_launch_dwpw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_dwpwx6_eligible(const fp_op& op);   // DWPW with FP_OPF_SPLIT3: depthwise on the VALU, 1x1 on the split MFMA (dwpwx6.hip)
+long fp_dwpwx6_w_floats(const fp_op& op);
+int fp_launch_dwpwx6(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwpw_persistent(const fp_op& op);   // true: dwpw_persist_kernel / dwpw_wp_kernel, false: dwpw_kernel
 bool fp_dwpw_wave_private(const fp_op& op); // true: dwpw_wp_kernel (projection weights resident in LDS)
 bool fp_blazepair_supported(const fp_op& op);   // two stride-1 24 -> 24 BlazeBlocks in one kernel (blazepair.hip)

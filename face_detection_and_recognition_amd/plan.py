@@ -436,6 +436,29 @@ class PlanBuilder:
         self.alg_bytes.append(2 * 4 * self.N * pix * 24 * 4)      # two blocks, four tensor passes each
         return out
 
+    DWPW_X6 = os.environ.get("FP_DWPW_X6", "1") == "1"    # the dw -> 1x1 op with its 1x1 on the split MFMA (csrc/dwpwx6.hip)
+
+    @classmethod
+    def dwpwx6_ok(cls, x, out, G, stride, res, shuffle, out_slope, out_act):
+        """Mirror of fp_dwpwx6_eligible (csrc/dwpwx6.hip)."""
+        if not (cls.X6 and cls.DWPW_X6) or out_slope is not None or out_act not in (L.ACT_NONE, L.ACT_SILU) or stride not in (1, 2):
+            return False
+        if G % 32 or G > 256 or out.C not in (64, 128) or out.W % 4 or out.cmul != 1 or x.buf.rowpad or out.buf.rowpad:
+            return False
+        if out.C != 128:      # measured on YOLOv5n-face (256 images): 128 -> 128 at 40x40 278 -> 246 us, 80x80 stride 2 367 / 298 ->
+            return False      # 345 / 248; 64 -> 64 at 80x80 420 -> 440 (the depthwise phase, not the 1x1, bounds the narrow form)
+        ohw = out.H * out.W
+        if x.buf.ld % 4 or (x.buf.off + x.coff) % 4 or x.buf.ns % 4 or x.buf.ns < x.H * x.W * x.buf.ld:
+            return False
+        for v in [out] + ([res] if res is not None else []):
+            if v.buf.ld % 4 or (v.buf.off + v.coff) % 4 or v.buf.ns != ohw * v.buf.ld:
+                return False
+        if res is not None and min(res.C, out.C) % 4:
+            return False
+        if shuffle and (res.C < out.C or out.buf.ld < 2 * out.C):
+            return False
+        return True
+
     def dwpw(self, x, dw_w, dw_scale, dw_bias, dw_slope, pw_w, pw_scale, pw_bias, out, stride, res=None,
              out_slope=None, out_act=L.ACT_NONE, shuffle=False):
         """Fused Depth_Wise tail (mobile_facenet.py:72-85): dw3x3 stride s (+BN affine, +PReLU) -> 1x1 (+BN affine)
@@ -451,6 +474,7 @@ class PlanBuilder:
         else:
             assert out.coff == 0 and out.buf.ld == out.C or out_act != L.ACT_NONE
         op = self._base(L.OP_DWPW, x, out, out.H, out.W)
+        split = self.dwpwx6_ok(x, out, G, stride, res, shuffle, out_slope, out_act)
         op.act2 = out_act
         op.Cout = out.C
         op.KH = op.KW = 3
@@ -461,8 +485,17 @@ class PlanBuilder:
         op.w_off = self.add_weight(np.concatenate([pack_dw_weight(dw_w, G), pad_vec(dw_scale, G), pad_vec(dw_bias, G),
                                                    pad_vec(slope, G)]))
         c4 = round_up(out.C, 4)
-        op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(pw_w, G, out.C), pad_vec(pw_scale, c4),
-                                                       pad_vec(pw_bias, c4)]))
+        if split:
+            # the 1x1 as three bf16 planes [G / 32][3][N][32] (csrc/dwpwx6.hip), then [N] BN scale, [N] BN bias
+            full = np.zeros((out.C, G), np.float32)
+            full[:cout] = np.asarray(pw_w, np.float32).reshape(cout, G)
+            w3 = split3_bf16(full).reshape(3, out.C, G // 32, 32).transpose(2, 0, 1, 3)
+            op.flags |= L.OPF_SPLIT3
+            op.slope_off = self.add_weight(np.concatenate([np.ascontiguousarray(w3).reshape(-1).view(np.float32),
+                                                           pad_vec(pw_scale, c4), pad_vec(pw_bias, c4)]))
+        else:
+            op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(pw_w, G, out.C), pad_vec(pw_scale, c4),
+                                                           pad_vec(pw_bias, c4)]))
         if out_slope is not None:
             assert res is None
             op.bias_off = self.add_weight(pad_vec(out_slope, c4))
