@@ -91,6 +91,9 @@ SIGNATURES = {
     "fp_yolo_w_nms": (_I, [_P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "fp_row_inv_norm": (_I, [_P, _I64, _I, _P, _P]),
     "fp_cosine_filter": (_I, [_P, _P, _I64, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "fp_split3_bytes": (_SZ, [_I, _I]),
+    "fp_split3_rows": (_I, [_P, _I, _I, _P, _P]),
+    "fp_cosine_filter_x6": (_I, [_P, _P, _I64, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
     "fp_l2_mean_thres": (_I, [_P, _I, _I, _P, _P, _P]),
     "fp_l2_filter": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P]),
     "fp_resize_standardize": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),

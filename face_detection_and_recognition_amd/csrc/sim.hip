@@ -7,9 +7,12 @@
 //    tile) so the M x Nr score matrix is never written to HBM.
 //  * L2-to-class-mean filter, the reference's actual semantics
 //    (similar_face_filtering/filter_faces_using_reference.py:71-100,183-197).
-#include "common.h"
+#include "split.h"
 
 namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
 constexpr int BM = 128, BN = 128, KC = 32, LDA = KC + 4;
 
@@ -121,6 +124,161 @@ __global__ __launch_bounds__(256) void cosine_tile_kernel(const float* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same filter with S = G R^T on the bf16 matrix cores (fp32-equivalent split arithmetic, split.h): the fp32 kernel above
+// reaches 117 TFLOP/s = 74 % of the fp32 MFMA peak; six bf16 products per fp32 product have a peak of 417.
+//   * R is split ONCE into three bf16 planes [D / 32][3][Npad][32] (split3_rows_kernel; the reference set of a filter run is
+//     fixed) -- the B operand, streamed slab by slab through LDS by LDS-DMA, double-buffered, one barrier per slab;
+//   * a workgroup = 4 waves x (MT x 16) gallery rows x 128 reference columns; a wave's A slab goes global -> registers -> split
+//     (as pwx6_kernel); column chunks of one row tile are adjacent in the grid, so the gallery rows are re-read from L2;
+//   * swapped operands: a lane holds 4 consecutive COLUMNS of one gallery row per accumulator -> the row max over the lane's
+//     32 columns is plain VALU, then two shuffles across the four k-groups, one 64-bit atomicMax per row and workgroup.
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ R, int Nr, int D, int Npad,
+                                                          unsigned short* __restrict__ out) {
+  // one thread per (row n < Npad, 8 consecutive k): out[((k / 32) * 3 + pl) * Npad + n][k % 32]
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int k8 = D / 8;
+  if (i >= (long)Npad * k8) return;
+  const int n = (int)(i / k8), k = (int)(i - (long)n * k8) * 8;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  if (n < Nr) {
+    a = *(const f32x4*)(R + (long)n * D + k);
+    b = *(const f32x4*)(R + (long)n * D + k + 4);
+  }
+  const fp_frag3 f = fp_split8(a, b);
+  unsigned short* o = out + ((long)((k / 32) * 3) * Npad + n) * 32 + (k % 32);
+  *(u32x4*)o = f.h;
+  *(u32x4*)(o + (long)Npad * 32) = f.m;
+  *(u32x4*)(o + 2L * Npad * 32) = f.l;
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, MT == 4 ? 2 : 3) void cosine_x6_kernel(const float* __restrict__ G, const float* __restrict__ ginv,
+                                                                          long M, const unsigned short* __restrict__ R3,
+                                                                          const float* __restrict__ rinv, int Nr, int Npad, int D,
+                                                                          unsigned long long* __restrict__ packed) {
+  constexpr int NT16 = 8, NC = 128, SLAB = 3 * NC * 32, XBM = 4 * MT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Bl = (unsigned short*)smem_raw;        // [2][3][NC][32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int nchunk = Npad / NC;
+  const int chunk = blockIdx.x % nchunk;
+  const long row0 = (long)(blockIdx.x / nchunk) * XBM + wave * (MT * 16);
+  const int c0 = chunk * NC;
+  const int KS = D / 32;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int ks) {
+    unsigned char* dst = (unsigned char*)(Bl + (ks & 1) * SLAB);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned char* src = (const unsigned char*)(R3 + ((long)(ks * 3 + pl) * Npad + c0) * 32) + lane * 16;
+#pragma unroll
+      for (int j = 0; j < NT16 / 4; ++j) {
+        const int c = j * 4 + wave;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(src + c * 1024), (lds_ptr)(dst + (pl * NC * 32 + c * 512) * 2), 16, 0, 0);
+      }
+    }
+  };
+  const float* arow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    long r = row0 + 16 * t + l15;
+    r = r < M ? r : M - 1;
+    arow[t] = G + r * D + 8 * q;
+  }
+  f32x4 araw[MT][2];
+  auto load_a = [&](int ks) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      araw[t][0] = *(const f32x4*)(arow[t] + 32 * ks);
+      araw[t][1] = *(const f32x4*)(arow[t] + 32 * ks + 4);
+    }
+  };
+  f32x4 acc[MT][NT16];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) acc[t][n] = z;
+
+  stage(0);
+  load_a(0);
+  for (int ks = 0; ks < KS; ++ks) {
+    fp_frag3 af[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) af[t] = fp_split8(araw[t][0], araw[t][1]);
+    __syncthreads();
+    if (ks + 1 < KS) {
+      stage(ks + 1);
+      load_a(ks + 1);
+    }
+    const unsigned short* Bc = Bl + (ks & 1) * SLAB + (l15 * 32 + 8 * q);
+    fp_frag3 bf[2];
+    auto ldb = [&](int n, fp_frag3& b) {
+      b.h = *(const u32x4*)(Bc + n * 512);
+      b.m = *(const u32x4*)(Bc + NC * 32 + n * 512);
+      b.l = *(const u32x4*)(Bc + 2 * NC * 32 + n * 512);
+    };
+    ldb(0, bf[0]);
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) {
+      if (n + 1 < NT16) ldb(n + 1, bf[(n + 1) & 1]);
+      const fp_frag3& b = bf[n & 1];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][n] = fp_mfma_x6(b.h, b.m, b.l, af[t].h, af[t].m, af[t].l, acc[t][n]);
+    }
+  }
+
+  // epilogue: lane = gallery row 16 t + l15, reference columns c0 + 16 n + 4 q + i
+  f32x4 rn[NT16];
+#pragma unroll
+  for (int n = 0; n < NT16; ++n) {
+    const int col = c0 + 16 * n + 4 * q;
+    if (col + 3 < Nr) {
+      rn[n] = *(const f32x4*)(rinv + col);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rn[n][i] = col + i < Nr ? rinv[col + i] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const long m = row0 + 16 * t + l15;
+    const float gi = m < M ? ginv[m] : 0.f;
+    float best = -__builtin_huge_valf();
+    int bidx = 0x7FFFFFFF;
+#pragma unroll
+    for (int n = 0; n < NT16; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = c0 + 16 * n + 4 * q + i;
+        if (col < Nr) {
+          const float sv = acc[t][n][i] * gi * rn[n][i];
+          if (sv > best || (sv == best && col < bidx)) {
+            best = sv;
+            bidx = col;
+          }
+        }
+      }
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {                  // the four k-group lanes of this row
+      const float ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bidx, off);
+      if (ob > best || (ob == best && oi < bidx)) {
+        best = ob;
+        bidx = oi;
+      }
+    }
+    if (q == 0 && m < M && bidx != 0x7FFFFFFF) {
+      const unsigned long long key = ((unsigned long long)f2ord(best) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned int)bidx);
+      atomicMax(&packed[m], key);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cosine_finalize_kernel(const unsigned long long* __restrict__ packed, long M,
                                                               float tau, float* __restrict__ best,
                                                               int* __restrict__ arg, unsigned char* __restrict__ keep) {
@@ -225,6 +383,52 @@ int fp_cosine_filter(const float* G, const float* ginv, int64_t M, const float* 
   dim3 grid((unsigned)fp_ceil_div(M, BM), (unsigned)fp_ceil_div(Nr, BN));
   hipLaunchKernelGGL(cosine_tile_kernel, grid, dim3(256), 0, s, G, ginv, (long)M, R, rinv, Nr, D,
                      (unsigned long long*)packed);
+  FP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cosine_finalize_kernel, dim3((unsigned)fp_ceil_div(M, 256)), dim3(256), 0, s,
+                     (const unsigned long long*)packed, (long)M, tau, best, arg, keep);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+
+size_t fp_split3_bytes(int Nr, int D) { return (size_t)(D / 32) * 3 * (size_t)fp_round_up(Nr, 128) * 32 * 2; }
+
+int fp_split3_rows(const float* R, int Nr, int D, void* out, void* stream) {
+  if (!R || !out || Nr <= 0 || D <= 0) return FP_ERR_INVALID_ARG;
+  if (D % 32 || ((uintptr_t)R) % 16 || ((uintptr_t)out) % 16) return FP_ERR_ALIGNMENT;
+  const int Npad = (int)fp_round_up(Nr, 128);
+  const long items = (long)Npad * (D / 8);
+  hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)fp_ceil_div(items, 256)), dim3(256), 0, (hipStream_t)stream, R, Nr, D, Npad,
+                     (unsigned short*)out);
+  FP_CHECK_LAUNCH();
+  return FP_OK;
+}
+
+int fp_cosine_filter_x6(const float* G, const float* ginv, int64_t M, const void* R3, const float* rinv, int Nr, int D,
+                        float tau, float* best, int32_t* arg, uint8_t* keep, uint64_t* packed, void* stream) {
+  if (!G || !ginv || !R3 || !rinv || !best || !arg || !keep || !packed) return FP_ERR_INVALID_ARG;
+  if (M < 0 || Nr <= 0 || D <= 0) return FP_ERR_INVALID_ARG;
+  if (D % 32 || ((uintptr_t)G) % 16 || ((uintptr_t)R3) % 16 || ((uintptr_t)rinv) % 16) return FP_ERR_ALIGNMENT;
+  if (M == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(packed, 0, (size_t)M * sizeof(uint64_t), s) != hipSuccess) {
+    fp_set_hip_error(hipGetLastError());
+    return FP_ERR_LAUNCH;
+  }
+  const int Npad = (int)fp_round_up(Nr, 128);
+  const long nchunk = Npad / 128;
+  constexpr int lds = 2 * 3 * 128 * 32 * 2;
+  // 256-row tiles (two workgroups per CU) when they fill several rounds of workgroups, else 128-row tiles (three per CU)
+  const long big = (M + 255) / 256 * nchunk;
+  if (big >= 2048) {
+    if (big >= (1L << 31)) return FP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((cosine_x6_kernel<4>), dim3((unsigned)big), dim3(256), lds, s, G, ginv, (long)M, (const unsigned short*)R3, rinv,
+                       Nr, Npad, D, (unsigned long long*)packed);
+  } else {
+    const long tiles = (M + 127) / 128 * nchunk;
+    hipLaunchKernelGGL((cosine_x6_kernel<2>), dim3((unsigned)tiles), dim3(256), lds, s, G, ginv, (long)M, (const unsigned short*)R3, rinv,
+                       Nr, Npad, D, (unsigned long long*)packed);
+  }
   FP_CHECK_LAUNCH();
   hipLaunchKernelGGL(cosine_finalize_kernel, dim3((unsigned)fp_ceil_div(M, 256)), dim3(256), 0, s,
                      (const unsigned long long*)packed, (long)M, tau, best, arg, keep);

@@ -47,6 +47,8 @@ class FacePipeline:
     def set_reference(self, reference):
         self.reference = None if reference is None else reference.to(self.dev, torch.float32).contiguous()
         self.rinv = None if reference is None else S.row_inv_norm(self.reference)
+        # the reference set split once into bf16 planes for the split-MFMA cosine kernel (similarity.split3_rows)
+        self.ref3 = None if reference is None or self.reference.shape[1] % 32 else S.split3_rows(self.reference)
 
     # -- stages ----------------------------------------------------------------------------------
     def detect(self, frames, max_det=-1):
@@ -160,7 +162,7 @@ class FacePipeline:
     def filter(self, emb):
         if self.reference is None or emb.shape[0] == 0:
             return None
-        return S.cosine_filter(emb, self.reference, self.tau, rinv=self.rinv)
+        return S.cosine_filter(emb, self.reference, self.tau, rinv=self.rinv, r3=self.ref3)
 
     # -- whole step ------------------------------------------------------------------------------
     def step(self, frames):

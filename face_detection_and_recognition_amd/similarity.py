@@ -23,9 +23,22 @@ def row_inv_norm(x):
     return out
 
 
-def cosine_filter(G, R, tau, ginv=None, rinv=None):
+def split3_rows(R):
+    """The reference rows as three bf16 planes for cosine_filter's split-MFMA kernel (csrc/split.h: exact three-way split of
+    every fp32 value; layout [D / 32][3][round_up(Nr, 128)][32]).  Done once per reference set."""
+    R = _f32c(R)
+    Nr, D = R.shape
+    lib = L.load()
+    out = torch.empty((lib.fp_split3_bytes(Nr, D),), dtype=torch.uint8, device=R.device)
+    L.check(lib.fp_split3_rows(L.ptr(R), Nr, D, L.ptr(out), L.current_stream(R.device)), "fp_split3_rows")
+    return out
+
+
+def cosine_filter(G, R, tau, ginv=None, rinv=None, r3=None, x6=None):
     """G (M, D) gallery, R (Nr, D) reference -> best (M,), arg (M,) int32, keep (M,) bool.
-    The M x Nr score matrix is never materialised."""
+    The M x Nr score matrix is never materialised.  x6 (default: PlanBuilder.X6 and D a multiple of 32): S = G R^T on the
+    bf16 matrix cores with fp32-equivalent split arithmetic (r3 = split3_rows(R), computed here when not passed in)."""
+    from .plan import PlanBuilder
     G, R = _f32c(G), _f32c(R)
     M, D = G.shape
     Nr = R.shape[0]
@@ -37,9 +50,17 @@ def cosine_filter(G, R, tau, ginv=None, rinv=None):
     arg = torch.empty((M,), dtype=torch.int32, device=dev)
     keep = torch.empty((M,), dtype=torch.uint8, device=dev)
     packed = torch.empty((M,), dtype=torch.int64, device=dev)
-    L.check(L.load().fp_cosine_filter(L.ptr(G), L.ptr(ginv), M, L.ptr(R), L.ptr(rinv), Nr, D, float(tau),
-                                      L.ptr(best), L.ptr(arg), L.ptr(keep), L.ptr(packed), L.current_stream(dev)),
-            "fp_cosine_filter")
+    if x6 is None:
+        x6 = PlanBuilder.X6 and D % 32 == 0
+    if x6:
+        r3 = split3_rows(R) if r3 is None else r3
+        L.check(L.load().fp_cosine_filter_x6(L.ptr(G), L.ptr(ginv), M, L.ptr(r3), L.ptr(rinv), Nr, D, float(tau),
+                                             L.ptr(best), L.ptr(arg), L.ptr(keep), L.ptr(packed), L.current_stream(dev)),
+                "fp_cosine_filter_x6")
+    else:
+        L.check(L.load().fp_cosine_filter(L.ptr(G), L.ptr(ginv), M, L.ptr(R), L.ptr(rinv), Nr, D, float(tau),
+                                          L.ptr(best), L.ptr(arg), L.ptr(keep), L.ptr(packed), L.current_stream(dev)),
+                "fp_cosine_filter")
     return best, arg, keep.bool()
 
 

@@ -414,6 +414,20 @@ int fp_cosine_filter(const float* G, const float* ginv, int64_t M,
                      uint64_t* packed, void* stream);
 
 /*
+ * The same filter with S = G R^T on the bf16 matrix cores, fp32-equivalent split arithmetic (ABI 5, csrc/split.h): the
+ * reference rows are split ONCE into three bf16 planes (fp_split3_rows: out holds fp_split3_bytes(Nr, D) bytes, layout
+ * [D / 32][3][round_up(Nr, 128)][32] bf16, zero rows in the padding; D a multiple of 32), then every gallery batch runs
+ * fp_cosine_filter_x6 against them.  Same results within fp32 rounding (best: 1e-6; arg: equal unless two scores tie within
+ * it), 2x the rate of the fp32-MFMA kernel at 1 M x 10 k x 512.  rinv must be 16-byte aligned.
+ */
+size_t fp_split3_bytes(int Nr, int D);
+int fp_split3_rows(const float* R, int Nr, int D, void* out, void* stream);
+int fp_cosine_filter_x6(const float* G, const float* ginv, int64_t M,
+                        const void* R3, const float* rinv, int Nr, int D, float tau,
+                        float* best, int32_t* arg, uint8_t* keep,
+                        uint64_t* packed, void* stream);
+
+/*
  * get_ref_mean_vec_and_thres_from_imgs (sff/filter_faces_using_reference.py:71-100):
  * mean over the R reference rows, thres = max_i ||mean - f_i||_2.  out_mean [D], out_thres [1].
  */

@@ -1091,13 +1091,22 @@ def test_cosine_filter_ragged_and_large(dev):
     for M, Nr, D in ((1, 1, 512), (130, 257, 512), (1000, 77, 128), (4096, 3000, 512)):
         G = rng.normal(0, 1, (M, D)).astype(np.float32)
         R = rng.normal(0, 1, (Nr, D)).astype(np.float32)
-        best, arg, keep = S.cosine_filter(torch.from_numpy(G).to(dev), torch.from_numpy(R).to(dev), 0.05)
         rb, ra, rk, Smat = similarity_ref.cosine_filter(G, R, 0.05)
-        np.testing.assert_allclose(best.cpu().numpy(), rb, rtol=0, atol=1e-4)
-        a = arg.cpu().numpy()
-        # the argmax may differ only where two scores tie within rounding
-        bad = a != ra
-        assert np.all(np.abs(Smat[np.arange(M), a][bad] - rb[bad]) < 1e-5)
+        S64 = (G.astype(np.float64) / np.linalg.norm(G.astype(np.float64), axis=1, keepdims=True)) @ \
+              (R.astype(np.float64) / np.linalg.norm(R.astype(np.float64), axis=1, keepdims=True)).T
+        got = {}
+        for x6 in (False, True):   # fp32-MFMA kernel / split-MFMA kernel (csrc/sim.hip cosine_x6_kernel; D = 512 and 128)
+            best, arg, keep = S.cosine_filter(torch.from_numpy(G).to(dev), torch.from_numpy(R).to(dev), 0.05, x6=x6)
+            got[x6] = best.cpu().numpy()
+            np.testing.assert_allclose(got[x6], rb, rtol=0, atol=1e-4)
+            a = arg.cpu().numpy()
+            # the argmax may differ only where two scores tie within rounding
+            bad = a != ra
+            assert np.all(np.abs(Smat[np.arange(M), a][bad] - rb[bad]) < 1e-5)
+            np.testing.assert_array_equal(keep.cpu().numpy(), got[x6] >= 0.05)
+        # the split arithmetic is not less accurate than the fp32 chain (fp64 as the truth)
+        e32, e6 = np.abs(got[False] - S64.max(1)).max(), np.abs(got[True] - S64.max(1)).max()
+        assert e6 <= 2.0 * e32 + 1e-7, (e6, e32)
 
 
 # ------------------------------------------------------------------ YOLOv5-face
