@@ -388,6 +388,15 @@ def run_pipeline(args):
                          "(one fp32 rounding); parity tests use the same bounds as for the fp32-MFMA kernels and check "
                          "against fp64 that the error is not above the fp32 oracle's own; everything else fp32 throughout"}
         if world == 1 and args.mfma == "bf16x6" and not args.no_fp32_leg:
+            # (both legs: single stream, every step self-contained -- FacePipeline.step -- so that they compare with each other)
+            for k in range(2):
+                step(k)
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            nq = sum(step(k) for k in range(20))
+            torch.cuda.synchronize()
+            dq = time.perf_counter() - tq
+            arith["split_mfma_single_stream"] = {"ms_per_step": round(dq / 20 * 1e3, 3), "faces_per_s": round(nq / dq, 1), "steps": 20}
             Depth_Wise.X6 = False
             try:
                 for k in range(3):
