@@ -76,13 +76,14 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (OH <= 0 || OW <= 0) return FP_ERR_INVALID_ARG;
   const bool ext_in = op.kind == FP_OP_YSTEM_U8 || op.kind == FP_OP_STEM_U8;   // input in an external buffer (checked at launch)
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
-                    op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
-  if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
+                    op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_BLAZECHAIN || op.kind == FP_OP_YSTEM || ext_in) ? op.Cout : op.Cin;
+  if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_BLAZECHAIN && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
   if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW)) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_IN_DW) && (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3))) return FP_ERR_INVALID_ARG;
-  if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW) return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW && op.kind != FP_OP_BLAZECHAIN)
+    return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_DWPW && !fp_dwpwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
@@ -122,7 +123,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.in_ns < 0 || op.out_ns < 0) return FP_ERR_INVALID_ARG;
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
-      op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_YSTEM || ext_in) {
+      op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_BLAZECHAIN ||
+      op.kind == FP_OP_YSTEM || ext_in) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -168,6 +170,11 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (!span_ok(op.w_off, 2 * 9 * 24, weight_floats) || !span_ok(op.scale_off, 2 * 24, weight_floats) ||
         !span_ok(op.slope_off, 2 * 768, weight_floats) || !span_ok(op.bias_off, 2 * 24, weight_floats))
       return FP_ERR_BOUNDS;
+  }
+  if (op.kind == FP_OP_BLAZECHAIN) {
+    // Cmid blocks back to back at w_off, each [1280 fp32 parameters][3 slabs of split 1x1 weights] (facepath.h BLAZECHAIN)
+    if (!fp_blazechain_supported(op)) return FP_ERR_UNSUPPORTED;
+    if (!span_ok(op.w_off, fp_blazechain_w_floats(op), weight_floats)) return FP_ERR_BOUNDS;
   }
   if (op.kind == FP_OP_DWBLOCK) {
     // w_off: expand packed as CONV (K = Cin, Npad = Cmid); scale_off: [15][Cmid]; slope_off: project packed as CONV
@@ -227,6 +234,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_DWPW:
     case FP_OP_DWBLOCK:
     case FP_OP_BLAZEPAIR:
+    case FP_OP_BLAZECHAIN:
     case FP_OP_YSTEM:
     case FP_OP_YSTEM_U8:
     case FP_OP_STEM_U8:
@@ -293,6 +301,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwpw_kernel<%d, %d, %d>", (int)fp_round_up(op->Cout, 32) / 32,
                (op->OW % 4 == 0) ? 4 : (op->OW % 2 == 0) ? 2 : 1, op->stride);
       return buf;
+    case FP_OP_BLAZECHAIN:
+      snprintf(buf, sizeof(buf), "blazechain96_kernel");
+      return buf;
     case FP_OP_BLAZEPAIR:
       snprintf(buf, sizeof(buf), "blazepair_kernel<%d>", op->W);
       return buf;
@@ -342,6 +353,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_DWBLOCK:
       return (op.flags & FP_OPF_SPLIT3) ? fp_launch_dwblock_x6(op, weights, arena, s) : fp_launch_dwblock(op, weights, arena, s);
     case FP_OP_BLAZEPAIR: return fp_launch_blazepair(op, weights, arena, s);
+    case FP_OP_BLAZECHAIN: return fp_launch_blazechain(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);
     case FP_OP_STEM_U8: return fp_launch_stem_u8(op, weights, arena, ext, n_ext, s);

@@ -87,6 +87,9 @@ bool fp_dwpw_wave_private(const fp_op& op); // true: dwpw_wp_kernel (projection 
 bool fp_blazepair_supported(const fp_op& op);   // two stride-1 24 -> 24 BlazeBlocks in one kernel (blazepair.hip)
 int fp_blazepair_band_rows(const fp_op& op);
 int fp_launch_blazepair(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_blazechain_supported(const fp_op& op);  // a run of stride-1 96 -> 96 BlazeBlocks on a 16 x 16 map in one kernel (blazechain.hip)
+int64_t fp_blazechain_w_floats(const fp_op& op);
+int fp_launch_blazechain(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwblock_supported(const fp_op& op); // whole Depth_Wise block shapes dwblock.hip is instantiated for
 int fp_launch_dwblock(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_dwblock_x6_supported(const fp_op& op);   // DWBLOCK with FP_OPF_SPLIT3: bf16x6 split-MFMA kernel (dwblockx6.hip)

@@ -6,6 +6,8 @@
   _weighted_non_max_suppression (:404-458)        -> fp_blaze_weighted_nms  (csrc/post.hip)
   _preprocess x/127.5-1 (:248-250)                -> LUT inside fp_resize_normalize (csrc/image.hip)
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -32,6 +34,12 @@ class BlazeBlock(_NoCompute):
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
     ROWPAD = True  # class-wide switch: False keeps every activation dense (A/B parity tests)
     PAIR = True    # class-wide switch: two consecutive stride-1 24 -> 24 blocks as ONE op (FP_OP_BLAZEPAIR, csrc/blazepair.hip)
+
+    CHAIN = os.environ.get("FP_BLAZE_CHAIN", "1") == "1"   # class-wide switch: a run of stride-1 96 -> 96 blocks on the 16 x 16 map as ONE op (FP_OP_BLAZECHAIN, csrc/blazechain.hip)
+
+    def chains(self):
+        """True if this block can be a member of an FP_OP_BLAZECHAIN run."""
+        return self.kernel_size == 3 and self.stride == 1 and self.in_channels == 96 and self.out_channels == 96
 
     def pairs_with(self, other, pb, x):
         """True if self followed by `other`, fed the row-padded view x, runs as one FP_OP_BLAZEPAIR."""
@@ -164,6 +172,11 @@ class BlazeFace(nn.Module):
         self.min_suppression_threshold = 0.3
         self.anchors = None
         self._plans = PlanCache()
+        # True: this network's plans run BESIDE another network's kernels (FacePipeline(two_streams=True)).  Ops whose
+        # workgroups own a whole CU are then not emitted: FP_OP_BLAZECHAIN holds 157 KB of LDS, so for its 75 us nothing of
+        # the other stream fits on the CUs and its own launch waits for them to drain -- measured 4.10 against 4.01 ms
+        # per two-stream step, although the detector alone gets 0.19 ms faster with it (DESIGN finding 30).
+        self.co_scheduled = False
         self._define_layers()
 
     def _define_layers(self):
@@ -236,7 +249,17 @@ class BlazeFace(nn.Module):
         # fused block).
         blocks = seq[2:]
 
+        def chain_len(i, h, w):    # blocks[i:i + n] on an h x w map run as one FP_OP_BLAZECHAIN (0: they do not)
+            if not (BlazeBlock.FUSE and BlazeBlock.CHAIN and not self.co_scheduled and PlanBuilder.X6 and (h, w) == (16, 16)):
+                return 0
+            n = 0
+            while i + n < len(blocks) and isinstance(blocks[i + n], BlazeBlock) and blocks[i + n].chains():
+                n += 1
+            return min(n, 16) if n >= 2 else 0
+
         def rowpad_for(i, h, w):   # should the input of blocks[i] (an h x w map) be row-padded?
+            if chain_len(i, h, w):     # the chain kernel reads a dense map
+                return False
             return i < len(blocks) and isinstance(blocks[i], BlazeBlock) and blocks[i].wants_rowpad_input(h, w)
 
         # F.pad(x, (1, 2, 1, 2)) + 5x5 stride-2 conv + ReLU (blazeface.py:118-120,195)
@@ -249,7 +272,13 @@ class BlazeFace(nn.Module):
         i = 0
         while i < len(blocks):
             blk = blocks[i]
-            if (isinstance(blk, BlazeBlock) and i + 1 < len(blocks) and isinstance(blocks[i + 1], BlazeBlock) and
+            nchain = chain_len(i, x.H, x.W)
+            if nchain and pb.blazechain_supported(x.view()):
+                y = pb.new_buf(16, 16, 96)
+                pb.blazechain(x.view(), [(npy(b.convs[0].weight), npy(b.convs[0].bias), npy(b.convs[1].weight), npy(b.convs[1].bias))
+                                         for b in blocks[i:i + nchain]], y.view())
+                i += nchain - 1
+            elif (isinstance(blk, BlazeBlock) and i + 1 < len(blocks) and isinstance(blocks[i + 1], BlazeBlock) and
                     blk.pairs_with(blocks[i + 1], pb, x.view())):
                 y = blk.emit_pair(blocks[i + 1], pb, x.view(), out_rowpad=rowpad_for(i + 2, x.H, x.W))
                 i += 1
@@ -299,7 +328,7 @@ class BlazeFace(nn.Module):
     def plan_for(self, N, frame_hw=None):
         if self._device().type != "cuda":
             raise L.FacepathError("BlazeFace runs only on a HIP device (model.to('cuda')); there is no CPU path")
-        return self._plans.get((N, frame_hw), lambda cache: self._build(N, cache, frame_hw))
+        return self._plans.get((N, frame_hw, self.co_scheduled), lambda cache: self._build(N, cache, frame_hw))
 
     # ------------------------------------------------------------------ inference
     def forward(self, x):

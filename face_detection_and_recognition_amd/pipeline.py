@@ -42,6 +42,8 @@ class FacePipeline:
         # k + 1 (the split-MFMA embedder kernels are matrix-core bound, the BlazeFace kernels vector-ALU / HBM bound, and
         # every kernel's last, partly empty round of workgroups is filled by the other stream's work)
         self.emb_stream = torch.cuda.Stream(device=self.dev) if two_streams else None
+        net = getattr(detector, "net", None)
+        self._co_net = net if hasattr(net, "co_scheduled") else None     # BlazeFace: no whole-CU ops beside the embedder's kernels
         self.set_reference(reference)
 
     def set_reference(self, reference):
@@ -51,9 +53,12 @@ class FacePipeline:
         self.ref3 = None if reference is None or self.reference.shape[1] % 32 else S.split3_rows(self.reference)
 
     # -- stages ----------------------------------------------------------------------------------
-    def detect(self, frames, max_det=-1):
+    def detect(self, frames, max_det=-1, beside=False):
         """frames (B, H, W, 3) u8 BGR on device -> (dets, counts, overflow or None).  max_det: -1 = the detector's
-        default cap, None = uncapped (the exact re-run after an overflow)."""
+        default cap, None = uncapped (the exact re-run after an overflow).  beside: the detector's kernels will run
+        beside the embedder's on the other stream (step_overlapped with two_streams)."""
+        if self._co_net is not None:      # selects the plan (blazeface.py plan_for): several pipelines may share one detector
+            self._co_net.co_scheduled = bool(beside)
         out = self.det.raw_batch(frames) if max_det == -1 else self.det.raw_batch(frames, max_det=max_det)
         return out if len(out) == 3 else (out[0], out[1], None)
 
@@ -109,7 +114,7 @@ class FacePipeline:
         while the host waits.  Returns the previous batch's result dict (None on the first call); flush() returns the
         last one.  Same kernels, same numbers as step(); a detector overflow (more survivors than the cap in some frame)
         falls back to the exact un-capped re-run for that batch."""
-        dets, counts, over = self.detect(frames)
+        dets, counts, over = self.detect(frames, beside=self.emb_stream is not None)
         items, info, nf = self.crops(frames, dets, counts)
         host = torch.empty((2,), dtype=torch.int32).pin_memory()
         both = nf if over is None else torch.stack([nf[0], over.sum().to(torch.int32)])

@@ -436,6 +436,41 @@ class PlanBuilder:
         self.alg_bytes.append(2 * 4 * self.N * pix * 24 * 4)      # two blocks, four tensor passes each
         return out
 
+    @staticmethod
+    def blazechain_supported(x):
+        """Mirror of fp_blazechain_supported (csrc/blazechain.hip): a dense 96-channel 16 x 16 map."""
+        return (not x.buf.rowpad and x.coff == 0 and x.C == 96 and x.buf.ld == 96 and x.cmul == 1 and x.H == 16 and x.W == 16)
+
+    def blazechain(self, x, blocks, out):
+        """A run of stride-1 96 -> 96 BlazeBlocks on the 16 x 16 map (blazeface.py:12-47,146-152) as ONE op
+        (FP_OP_BLAZECHAIN): blocks = ((dw_w, dw_b, pw_w, pw_b), ...); the tensors between them never reach HBM.  The 1x1
+        weights go in as three bf16 planes (split3_bf16), one slab per 32 input channels: include/facepath.h BLAZECHAIN."""
+        assert self.blazechain_supported(x) and 1 <= len(blocks) <= 16
+        assert out.C == 96 and out.coff == 0 and out.buf.ld == 96 and not out.buf.rowpad and (out.H, out.W) == (16, 16)
+        op = self._base(L.OP_BLAZECHAIN, x, out, 16, 16)
+        op.Cout = 96
+        op.KH = op.KW = 3
+        op.stride = 1
+        op.pad_t = op.pad_l = 1
+        op.act, op.res_mode, op.res_C = L.ACT_RELU, L.RES_ADD_BEFORE_ACT, 96
+        op.res_ld, op.res_ns, op.res_off, op.res_H, op.res_W = op.in_ld, op.in_ns, op.in_off, 16, 16
+        op.Cmid = len(blocks)
+        op.flags |= L.OPF_SPLIT3
+        chunks = []
+        for wd, bd, wp, bp in blocks:
+            assert wd.shape == (96, 1, 3, 3) and wp.shape[:2] == (96, 96)
+            par = np.zeros(1280, np.float32)
+            par[:864] = pack_dw_weight(wd, 96)
+            par[864:960] = pad_vec(bd, 96)
+            par[960:1056] = pad_vec(bp, 96)
+            w3 = split3_bf16(np.asarray(wp, np.float32).reshape(96, 96))          # [3][cout][cin]
+            w3 = w3.reshape(3, 96, 3, 32).transpose(2, 0, 1, 3)                    # [slab][plane][cout][32]
+            chunks += [par, np.ascontiguousarray(w3).reshape(-1).view(np.float32)]
+        op.w_off = self.add_weight(np.concatenate(chunks))
+        self.ops.append(op)
+        self.alg_bytes.append(len(blocks) * 4 * self.N * 256 * 96 * 4)     # SURVEY 8(d): four tensor passes per block
+        return out
+
     DWPW_X6 = os.environ.get("FP_DWPW_X6", "1") == "1"    # the dw -> 1x1 op with its 1x1 on the split MFMA (csrc/dwpwx6.hip)
 
     @classmethod
@@ -868,7 +903,7 @@ class CompiledPlan:
             b_in = op.res_H * op.res_W * 3                       # u8 frame
         else:
             b_in = op.H * op.W * op.Cin * 4
-        cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_YSTEM, L.OP_YSTEM_U8,
+        cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_BLAZECHAIN, L.OP_YSTEM, L.OP_YSTEM_U8,
                                 L.OP_STEM_U8) else op.Cin
         oh, ow = (op.H, op.W) if k in (L.OP_COPY, L.OP_L2NORM) else (op.OH, op.OW)
         b_out = oh * ow * cout * 4 * (2 if op.res_mode == L.RES_SHUFFLE2 else 1)
@@ -895,6 +930,8 @@ class CompiledPlan:
             f = opix * (9 * op.Cin + op.Cin * op.Cout)
         elif k == L.OP_BLAZEPAIR:
             f = 2 * opix * (9 * op.Cin + op.Cin * op.Cout)
+        elif k == L.OP_BLAZECHAIN:
+            f = op.Cmid * opix * (9 * op.Cin + op.Cin * op.Cout)
         elif k == L.OP_DWBLOCK:
             f = op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cout)
         else:

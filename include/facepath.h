@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 5
+#define FP_ABI_VERSION 6
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -72,6 +72,8 @@ enum fp_op_kind {
                            blazeface.py:118-120,195) reading the u8 frames the same way; needs fp_plan_run_ext */
   FP_OP_BLAZEPAIR = 13, /* TWO consecutive stride-1 24 -> 24 BlazeBlocks (blazeface.py:12-47,122-152) in one kernel: the tensor
                            between them stays in an LDS ring.  Row-padded input, 128- or 64-pixel-wide map; see "BLAZEPAIR" */
+  FP_OP_BLAZECHAIN = 14, /* a RUN of fp_op.Cmid consecutive stride-1 96 -> 96 BlazeBlocks on the 16 x 16 map (blazeface.py:12-47,
+                           146-152) in one kernel: one image per workgroup stays in LDS for the whole run.  See "BLAZECHAIN" */
   FP_OP_DWBLOCK = 12    /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
                            dw3x3 stride 1 (+BN, PReLU) -> 1x1 project (+BN) [+ x]; the expanded tensor (Cmid channels)
                            lives in LDS only.  Shapes: see "DWBLOCK" below; anything else fails validation */
@@ -117,7 +119,7 @@ typedef struct fp_op {
   int64_t w_off, scale_off, bias_off, slope_off;
   int32_t act2;                    /* fused ops: activation of the SECOND conv's output (DWPW: FP_ACT_NONE / FP_ACT_SILU) */
   int32_t flags;                   /* FP_OPF_* bits (0 for dense tensors) */
-  int32_t Cmid;                    /* ABI 4.  DWBLOCK: channels of the expanded tensor (Depth_Wise `groups`); 0 elsewhere */
+  int32_t Cmid;                    /* ABI 4.  DWBLOCK: channels of the expanded tensor (Depth_Wise `groups`); BLAZECHAIN: number of blocks; 0 elsewhere */
   int32_t reserved0;               /* ABI 4.  must be 0 */
 } fp_op;
 
@@ -152,8 +154,12 @@ typedef struct fp_op {
  *                of every fp32 weight, w == h + m + l, planes = the top 16 bits of h, m, l) for the "bf16x6" kernels:
  *                fp32 operands on v_mfma_f32_16x16x32_bf16, six products per operand pair, fp32 accumulation, result as
  *                accurate as the fp32 fmaf chain (csrc/split.h; gfx950 has no TF32 and its fp32 MFMA runs at the
- *                vector rate).  Accepted: FP_OP_DWBLOCK with (Cin, H = W) in {(128, 14), (64, 28)}; layouts under
- *                "DWBLOCK".  The semantics of the op (mobile_facenet.py:67-88) do not change.
+ *                vector rate).  Accepted (exactly fp_plan_validate's list): FP_OP_DWBLOCK stride 1 with (Cin, H = W) in
+ *                {(128, 14), (128, 7), (64, 28)} and stride 2 with (Cin, Cmid, Cout, H) in {(64, 128, 64, 56),
+ *                (64, 256, 128, 28), (128, 512, 128, 14)} (layouts under "DWBLOCK"); FP_OP_CONV 1x1 stride 1 or 3x3 pad 1
+ *                stride 1 / 2, dense views, Cin and Cout multiples of 4 and >= 32 (weights [tap * ceil(Cin / 32) + slab][3
+ *                planes][Npad][32] bf16, zero rows / columns in the padding); FP_OP_DWPW 3x3 pad 1 with Cin a multiple of
+ *                32 (<= 256) and Cout 64 or 128; FP_OP_BLAZECHAIN (always).  The semantics of the ops do not change.
  */
 #define FP_OPF_SPLIT3 8
 /*
@@ -214,8 +220,13 @@ typedef struct fp_op {
  *            block's shortcut is its own input).  The two blocks' parameters back to back, each as for BLAZEBLOCK:
  *            w_off -> [2][9][24] taps, scale_off -> [2][24] depthwise bias, slope_off -> [2] packed 1x1 (K = 24,
  *            Npad = 32: 768 floats each), bias_off -> [2][24] 1x1 bias.
+ *   BLAZECHAIN : in = x, out = y (both dense, 96 channels, H = W = 16; in and out may be the same view), Cmid = number of
+ *            blocks (1..16); act = FP_ACT_RELU, res_mode = FP_RES_ADD_BEFORE_ACT (each block's shortcut is its own input);
+ *            flags = FP_OPF_SPLIT3: the 1x1 convs run as bf16x6 split MFMAs.  w_off -> Cmid blocks back to back, each
+ *            [1280 floats: [9][96] depthwise taps (ky*3 + kx), [96] depthwise bias, [96] 1x1 bias, 224 pad] followed by
+ *            three slabs (k = 32 s .. 32 s + 31) of [3 planes][96 output channels][32 k] bf16 (13 824 floats).
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -12,6 +12,7 @@ from face_detection_and_recognition_amd import similarity as S
 from face_detection_and_recognition_amd.modules.blazeface.blazeface import (BlazeBlock, BlazeFace, FinalBlazeBlock,
                                                                               generate_anchors)
 from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise, MobileFaceNet
+from face_detection_and_recognition_amd.modules.params import npy
 from face_detection_and_recognition_amd.plan import CompiledPlan, PlanBuilder
 from face_detection_and_recognition_amd.synth import synth_state_dict
 from oracle import blazeface_ref, image_ref, mobilefacenet_ref, similarity_ref
@@ -307,6 +308,60 @@ def test_blazepair_two_blocks_in_one_kernel_vs_oracle(dev, hw, n, out_rp):
     assert rel_err(outs[True], ref) < 1e-5
     np.testing.assert_allclose(outs[True], ref, rtol=1e-5, atol=2e-5)
     assert rel_err(outs[True], outs[False]) < 2e-6
+
+
+@pytest.mark.parametrize("nblk,n", [(7, 5), (2, 3), (1, 2), (7, 260)])
+def test_blazechain_run_of_blocks_in_one_kernel_vs_oracle(dev, nblk, n):
+    """FP_OP_BLAZECHAIN (csrc/blazechain.hip): nblk stride-1 96 -> 96 BlazeBlocks on the 16 x 16 map, the image kept in LDS
+    for the whole run (depthwise through DPP row shifts, the 1x1 convs as bf16x6 split MFMAs), against
+    blazeface_ref._blaze_block applied nblk times (torch fp32 on the CPU; blazeface.py:12-47,146-152) and against the
+    single-block launches (fp32 MFMA) on the same input.  Inputs with structure at the image border (the zero padding
+    comes from DPP bound_ctrl and the two zero rows in LDS): a constant image would hide a wrong neighbour."""
+    rng = np.random.default_rng(4000 + nblk + n)
+    blks = [BlazeBlock(96, 96) for _ in range(nblk)]
+    sds = []
+    for k, b in enumerate(blks):
+        sd = synth_state_dict(b.state_dict(), 2500 + k)
+        b.load_state_dict(sd)
+        sds.append(sd)
+    x = rng.normal(0, 1, (n, 96, 16, 16)).astype(np.float32)
+    x[:, :, :, 0] += 2.0          # left column, top row: distinct from the interior
+    x[:, :, 0, :] -= 1.5
+    outs = {}
+    for chain in (True, False):
+        pb = PlanBuilder(n)
+        inp = pb.new_buf(16, 16, 96)
+        if chain:
+            assert pb.blazechain_supported(inp.view()) and all(b.chains() for b in blks)
+            y = pb.new_buf(16, 16, 96)
+            pb.blazechain(inp.view(), [(npy(b.convs[0].weight), npy(b.convs[0].bias), npy(b.convs[1].weight), npy(b.convs[1].bias))
+                                       for b in blks], y.view())
+        else:
+            y = inp
+            for b in blks:
+                y = b.emit(pb, y.view())
+        plan = CompiledPlan(pb, dev)
+        names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+        if chain:
+            assert names == ["blazechain96_kernel"], names
+        else:
+            assert names.count("blazeblock_wps_kernel<96>") == nblk, names
+        plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+        yt = plan.buf_tensor(y, n)
+        if chain:
+            yt.fill_(float("nan"))
+        for _ in range(2):        # the op must not have modified its input
+            plan.run()
+        torch.cuda.synchronize()
+        outs[chain] = yt.permute(0, 3, 1, 2).cpu().numpy()
+    t = torch.from_numpy(x[:8])
+    for sd in sds:
+        t = blazeface_ref._blaze_block(sd, "", t, 1)
+    ref = t.numpy()
+    assert outs[True].shape == x.shape and np.isfinite(outs[True]).all()
+    assert rel_err(outs[True][:8], ref) < 1e-5
+    np.testing.assert_allclose(outs[True][:8], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    assert rel_err(outs[True], outs[False]) < 5e-6
 
 
 def test_blazeblock_fused_ragged_tail(dev):

@@ -73,11 +73,28 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
     assert names[6:9] == ["blazepair_kernel<64>"] * 3 and flags[6:9] == [both] * 3
     assert names[9].startswith("blazeblock_wp_kernel") and flags[9] == L.OPF_IN_ROWPAD
     i48 = [i for i, n in enumerate(names) if n.startswith("blazeblock_wps_kernel<48>")]
-    i96 = [i for i, n in enumerate(names) if n.startswith("blazeblock_wps_kernel<96>")]
-    assert len(i48) == 7 and len(i96) == 7 and i48 == list(range(11, 18))
+    assert len(i48) == 7 and i48 == list(range(11, 18))
     assert flags[10] == L.OPF_OUT_ROWPAD and flags[17] == L.OPF_IN_ROWPAD      # 24 -> 48 stride 2, last 48 -> 48 block
-    icopy = names.index("copy4_kernel")
-    assert flags[18] == 0 and flags[19] == 0 and icopy == 20 and flags[20] == L.OPF_OUT_ROWPAD   # unfused stride-2 block, then the copy
+    # unfused stride-2 block (dense), then the seven 96 -> 96 blocks of the 16 x 16 map as ONE op on the dense map
+    assert flags[18] == 0 and flags[19] == 0 and "copy4_kernel" not in names
+    assert names[20] == "blazechain96_kernel" and flags[20] == L.OPF_SPLIT3 and ops[20].Cmid == 7
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[20].Cmid = 8                               # an eighth block's parameters would lie behind this op's weights ...
+    bad[20].w_off = weights.size - 7 * 15104       # ... and here behind the blob
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[20].flags = 0                              # the chain exists only in the split-MFMA form
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
+    net = BlazeFace(True)
+    net.co_scheduled = True                        # plans that run beside another network's kernels: no whole-CU op
+    assert "blazechain96_kernel" not in [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in net._emit(4, frame_hw=(576, 1024))[0].finish()[0]]
+    BlazeBlock.CHAIN = False
+    try:
+        names2 = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0].finish()[0]]
+    finally:
+        BlazeBlock.CHAIN = True
+    i96 = [i for i, n in enumerate(names2) if n.startswith("blazeblock_wps_kernel<96>")]
+    assert len(i96) == 7 and names2.index("copy4_kernel") == 20      # the per-block kernels read a row-padded copy
     BlazeBlock.PAIR = False
     try:
         names1 = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0].finish()[0]]
