@@ -241,7 +241,7 @@ def run_pipeline(args):
         probe = [p.new_timer() for p in plans]
         for p, t in zip(plans, probe):
             p._timing = (t, bytes([1] * p.n_ops))
-        step(k)
+        finish(pipe.step(batches[k % N_BATCHES], beside=args.overlap == 2))   # the plans of the timed steps, alone on the GPU
         torch.cuda.synchronize()
         for p, t in zip(plans, probe):
             p._timing = None

@@ -170,10 +170,11 @@ class FacePipeline:
         return S.cosine_filter(emb, self.reference, self.tau, rinv=self.rinv, r3=self.ref3)
 
     # -- whole step ------------------------------------------------------------------------------
-    def step(self, frames):
+    def step(self, frames, beside=False):
         """One pass over a batch of frames.  Returns dict(n_faces, info, emb, best, arg, keep).
-        ``emb`` is a copy (the embedder's output lives in its plan arena and the next step overwrites it)."""
-        dets, counts, over = self.detect(frames)
+        ``emb`` is a copy (the embedder's output lives in its plan arena and the next step overwrites it).
+        beside: use the detector plan of the two-stream steps (measurement: bench.py's per-op probe pass)."""
+        dets, counts, over = self.detect(frames, beside=beside)
         items, info, nf = self.crops(frames, dets, counts)
         # the one host sync of the step: the face count (sizes the embedder batch) and the detector's overflow flag
         if over is None:
