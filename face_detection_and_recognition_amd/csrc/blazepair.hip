@@ -20,6 +20,10 @@
 // pixel is the same as two blazeblock_wp launches (fp32 MFMAs and VALU share the SIMD's ALU: tools/lab/coexec_lab.hip).
 #include "common.h"
 
+#ifndef FP_PAIR_ABLATE
+#define FP_PAIR_ABLATE 0   // lab only (DESIGN finding 31): 1 no per-row barrier, 2 no MFMAs, 4 no depthwise FMAs, 8 no row loads / stores -- wrong results, timing only
+#endif
+
 namespace {
 
 struct BlazePairArgs {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
             const f32x4 dbias = *(const f32x4*)(wl1 + 9 * C);
             f32x4 acc[4] = {dbias, dbias, dbias, dbias};
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < ((FP_PAIR_ABLATE & 4) ? 0 : 3); ++ky) {
               const int sl = ky == 0 ? s0 : ky == 1 ? s1 : s2;
               const f32x4 w0 = *(const f32x4*)(wl1 + (ky * 3 + 0) * C);
               const f32x4 w1 = *(const f32x4*)(wl1 + (ky * 3 + 1) * C);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
             }
           }
           // row y + 2 replaces row y - 1 in the register ring (if the next step computes a row)
-          if (y + 1 < p.H && i + 1 < nsteps) {
+          if (!(FP_PAIR_ABLATE & 8) && y + 1 < p.H && i + 1 < nsteps) {
             const char* rowp = inb + fp_uniform((long)(y + 2) * in_rb);
 #pragma unroll
             for (int j = 0; j < 6; ++j) x[s0][j] = *(const f32x4*)(rowp + voff_in + j * C * 4);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
           // (k & 3) + 8*(k >> 2) + 4h -- four consecutive channels per register quad, i.e. 16-byte pieces of a row-major
           // pixel, so the epilogue is 3 x (ds_read_b128, packed adds, ds_write_b128) instead of 16 + 16 scalar LDS accesses
 #pragma unroll
-          for (int kq = 0; kq < KG; ++kq) {
+          for (int kq = 0; kq < ((FP_PAIR_ABLATE & 2) ? 0 : KG); ++kq) {
             const f32x4 a = *(const f32x4*)(arow + kq * 8);
             m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf1[kq][0], a[0], m0, 0, 0, 0);
             FP_MFMA_ORDER();
@@ -193,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) *(f32x4*)&ry[(x0 + 1) * C + (lane + 64 * j) * 4] = z;
         }
+#if !(FP_PAIR_ABLATE & 1)
         __syncthreads();
+#endif
         if (i >= 2) {
           // ---- block 2: output row yo = y - 1 from ring rows yo-1, yo, yo+1 ----
           const int yo = y - 1;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
             const f32x4 dbias = *(const f32x4*)(wl2 + 9 * C);
             f32x4 acc[4] = {dbias, dbias, dbias, dbias};
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < ((FP_PAIR_ABLATE & 4) ? 0 : 3); ++ky) {
               const float* rr = ring + ((yo + ky) & 3) * RROW + rg_dw;      // ring row of y1 row yo - 1 + ky
               f32x4 xv[6];
 #pragma unroll
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
           for (int k = 0; k < 16; ++k) m0[k] = 0.f, m1[k] = 0.f;
           const float* arow = &At[lr * LDT + 4 * h];
 #pragma unroll
-          for (int kq = 0; kq < KG; ++kq) {
+          for (int kq = 0; kq < ((FP_PAIR_ABLATE & 2) ? 0 : KG); ++kq) {
             const f32x4 a = *(const f32x4*)(arow + kq * 8);
             m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf2[kq][0], a[0], m0, 0, 0, 0);
             FP_MFMA_ORDER();
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
               *(f32x4*)(opx + 8 * j) = v;
             }
           }
-          if (live) {
+          if (live && !((FP_PAIR_ABLATE & 8) && yo > y0)) {
             char* orow_g = outb + fp_uniform((long)yo * out_rb);
 #pragma unroll
             for (int j = 0; j < 3; ++j) *(f32x4*)(orow_g + voff_out + j * 1024) = *(const f32x4*)&At[(lane + 64 * j) * 4];

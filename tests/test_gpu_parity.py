@@ -362,6 +362,16 @@ def test_blazechain_run_of_blocks_in_one_kernel_vs_oracle(dev, nblk, n):
     assert rel_err(outs[True][:8], ref) < 1e-5
     np.testing.assert_allclose(outs[True][:8], ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
     assert rel_err(outs[True], outs[False]) < 5e-6
+    # in place (include/facepath.h BLAZECHAIN: in and out may be the same view): a workgroup reads its whole image first
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(16, 16, 96)
+    pb.blazechain(inp.view(), [(npy(b.convs[0].weight), npy(b.convs[0].bias), npy(b.convs[1].weight), npy(b.convs[1].bias))
+                               for b in blks], inp.view())
+    plan = CompiledPlan(pb, dev)
+    plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    plan.run()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(plan.buf_tensor(inp, n).permute(0, 3, 1, 2).cpu().numpy(), outs[True])
 
 
 def test_blazeblock_fused_ragged_tail(dev):

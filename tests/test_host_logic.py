@@ -115,7 +115,7 @@ def test_row_padded_views_in_the_blazeface_plan(lib):
     bad[1].in_off = 8                              # the pad row above image 0 would start before the arena
     assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
     bad = (L.FpOp * len(ops))(*ops)
-    bad[1].flags = 8                               # unknown flag bit
+    bad[1].flags = 64                              # unknown flag bit
     assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
     bad = (L.FpOp * len(ops))(*ops)
     bad[1].flags |= L.OPF_IN_C3                    # "fourth channel is padding" only makes sense on a 4-float pixel
