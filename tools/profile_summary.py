@@ -53,6 +53,9 @@ def main():
         for r in stats[:24]:
             o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
                     f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
+        o.write("\n`at::native::*copy*` / `__amd_rocclr_copyBuffer` / `fillBuffer*` rows with thousands of calls are SETUP (the synthetic "
+                "weights and frame batches uploaded tensor by tensor before the first step), not part of a step: a step launches "
+                "about 70 kernels, four of them torch's.\n")
         o.write("\nPMC (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, KiB, per launch average; "
                 "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the x2 being the gfx950 FETCH_SIZE correction):\n\n")
         o.write("| kernel | FETCH KiB | WRITE KiB | HBM MB / launch |\n|---|---|---|---|\n")
