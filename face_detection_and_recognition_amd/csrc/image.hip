@@ -8,7 +8,10 @@
 //   ((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2.
 // cv2 is absent offline, so this boundary is parity-unpinned against cv2 itself and pinned
 // against oracle/image_ref.py, which restates the same arithmetic in numpy.
-// One thread per canvas pixel; HBM-bound (reads each source byte once, writes 16 B per pixel).
+// resize_normalize_rows_kernel: a workgroup per (item, band of canvas rows), taps tabled once in LDS; the per-pixel
+// kernel remains for canvases with other than 4 channels.
+#include <stdlib.h>
+
 #include "common.h"
 #include "letterbox.h"
 
@@ -70,6 +73,79 @@ __global__ __launch_bounds__(256) void resize_normalize_kernel(ResizeArgs p) {
   }
 }
 
+// The same resize with the taps of an item computed ONCE per workgroup: a workgroup owns `rpb` canvas rows of one item,
+// builds the item's column taps and its rows' taps in LDS with the coef() of the per-pixel kernel (the table format of
+// letterbox.h: an 8-byte window per horizontal tap pair) and then turns out pixels with two 8-byte loads, four byte
+// permutes and 24-bit integer multiplies each -- instead of two fp64 divisions, two coef() evaluations and twelve byte
+// loads per pixel.  Bit-identical to resize_normalize_kernel (tests: test_resize_tabled_kernel_is_bit_exact).
+struct ResizeRowsArgs {
+  ResizeArgs a;
+  int rpb, bpi;           // canvas rows per workgroup, workgroups per item
+  fp_divisor cw_div;
+};
+
+__global__ __launch_bounds__(256) void resize_normalize_rows_kernel(ResizeRowsArgs q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lut = (float*)smem_raw;                               // [256]
+  fp_lb_tap* tabs = (fp_lb_tap*)(smem_raw + 1024);             // [cw] column taps, [rpb] row taps
+  const ResizeArgs& p = q.a;
+  const int tid = threadIdx.x;
+  const int item = blockIdx.x / q.bpi, y0 = (blockIdx.x - item * q.bpi) * q.rpb;
+  fp_resize_item it = p.items[item];
+  it.sx = min(max(it.sx, 0), p.fw - 1);
+  it.sy = min(max(it.sy, 0), p.fh - 1);
+  it.sw = min(max(it.sw, 1), p.fw - it.sx);
+  it.sh = min(max(it.sh, 1), p.fh - it.sy);
+  const bool item_ok = it.dw > 0 && it.dh > 0 && it.src_image >= 0 && it.src_image < p.n_frames;
+  lut[tid] = p.lut[tid];
+  for (int i = tid; i < p.cw + q.rpb; i += 256) {
+    fp_lb_tap t = {0, 0};
+    if (i < p.cw) {
+      if (item_ok && i >= it.dx && i < it.dx + it.dw) {
+        int s0, s1, a0, a1;
+        fp_lb_coef(i - it.dx, (double)it.sw / (double)it.dw, it.sw, s0, s1, a0, a1);
+        const int off0 = (it.sx + s0) * 3, off1 = (it.sx + s1) * 3;
+        const int base = min(off0, p.fw * 3 - 8);              // the 8-byte window never leaves the frame row
+        t.a = base;
+        t.b = (off0 - base) | ((off1 - base) << 3) | (a0 << 6) | (a1 << 18) | FP_LB_VALID;
+      }
+    } else {
+      const int y = y0 + (i - p.cw);
+      if (item_ok && y >= it.dy && y < it.dy + it.dh) {
+        int s0, s1, b0, b1;
+        fp_lb_coef(y - it.dy, (double)it.sh / (double)it.dh, it.sh, s0, s1, b0, b1);
+        t.a = (it.sy + s0) | ((it.sy + s1) << 16);
+        t.b = b0 | (b1 << 12) | FP_LB_VALID;
+      }
+    }
+    tabs[i] = t;
+  }
+  __syncthreads();
+  const uint8_t* frame = p.frames + (long)(item_ok ? it.src_image : 0) * p.fh * p.fw * 3;
+  const long row_bytes = (long)p.fw * 3;
+  const int rows = min(q.rpb, p.ch - y0);
+  const int npx = rows * p.cw;
+  float* out = p.canvas + ((long)item * p.ch + y0) * p.cw * 4;
+  // four pixels per thread and pass: the eight window loads are issued before the first pixel is finished
+  for (int i0 = tid; i0 < npx; i0 += 4 * 256) {
+    fp_lb_raw raw[4];
+    fp_lb_tap xt[4], yt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = min(i0 + 256 * k, npx - 1);
+      const int r = (int)fp_fastdiv((unsigned)i, q.cw_div), x = i - r * p.cw;
+      xt[k] = tabs[x];
+      yt[k] = tabs[p.cw + r];
+      raw[k] = fp_lb_issue(frame, row_bytes, xt[k], yt[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + 256 * k;
+      if (i < npx) *(f32x4*)(out + (long)i * 4) = fp_lb_finish(raw[k], xt[k], yt[k], lut, p.pad_value, p.swap_rb);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int fp_resize_normalize(const uint8_t* frames, int n_frames, int frame_h, int frame_w,
@@ -82,6 +158,21 @@ extern "C" int fp_resize_normalize(const uint8_t* frames, int n_frames, int fram
   if (n_items == 0) return FP_OK;
   ResizeArgs a{frames, items, canvas, lut256, n_frames, frame_h, frame_w, n_items, canvas_h, canvas_w, canvas_c,
                pad_value, swap_rb};
+  // tabled form: 16-byte pixels, a frame row of at least 8 bytes, rows / offsets that fit the table fields (letterbox.h)
+  if (canvas_c == 4 && frame_w >= 3 && frame_w <= 32767 && frame_h <= 65535 && canvas_w >= 2 && canvas_w <= 4096 &&
+      ((uintptr_t)canvas) % 16 == 0 && !getenv("FP_RESIZE_PER_PIXEL")) {
+    ResizeRowsArgs q;
+    q.a = a;
+    q.rpb = (int)min((long)canvas_h, max(1L, 8192L / canvas_w));      // ~8 k pixels per workgroup
+    q.bpi = (int)fp_ceil_div(canvas_h, q.rpb);
+    q.cw_div = fp_make_divisor((unsigned)canvas_w);
+    if ((long)n_items * q.bpi < (1L << 31)) {
+      const size_t lds = 1024 + (size_t)(canvas_w + q.rpb) * sizeof(fp_lb_tap);
+      hipLaunchKernelGGL(resize_normalize_rows_kernel, dim3((unsigned)((long)n_items * q.bpi)), dim3(256), lds, (hipStream_t)stream, q);
+      FP_CHECK_LAUNCH();
+      return FP_OK;
+    }
+  }
   const long total = (long)n_items * canvas_h * canvas_w;
   hipLaunchKernelGGL(resize_normalize_kernel, dim3((unsigned)fp_ceil_div(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, a);

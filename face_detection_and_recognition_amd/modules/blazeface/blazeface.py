@@ -33,7 +33,7 @@ class BlazeBlock(_NoCompute):
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pair (A/B parity tests)
     ROWPAD = True  # class-wide switch: False keeps every activation dense (A/B parity tests)
-    PAIR = True    # class-wide switch: two consecutive stride-1 24 -> 24 blocks as ONE op (FP_OP_BLAZEPAIR, csrc/blazepair.hip)
+    PAIR = os.environ.get("FP_BLAZE_PAIR", "1") == "1"    # class-wide switch: two consecutive stride-1 24 -> 24 blocks as ONE op (FP_OP_BLAZEPAIR, csrc/blazepair.hip)
 
     CHAIN = os.environ.get("FP_BLAZE_CHAIN", "1") == "1"   # class-wide switch: a run of stride-1 96 -> 96 blocks on the 16 x 16 map as ONE op (FP_OP_BLAZECHAIN, csrc/blazechain.hip)
 

@@ -147,7 +147,7 @@ def test_pipeline_step_overlapped_equals_step(dev, two_streams):
     ref = W.make_reference(300, dev)
     pipe = FacePipeline(det, emb, ref, tau=0.1, two_streams=two_streams)
     batches = [W.make_frames(6, dev, seed=40 + i) for i in range(5)]
-    want = [pipe.step(b) for b in batches]
+    want = [pipe.step(b, beside=two_streams) for b in batches]     # the detector plan step_overlapped will use (blazeface.py co_scheduled)
     got = [pipe.step_overlapped(b) for b in batches]
     assert got[0] is None
     got = got[1:] + [pipe.flush()]

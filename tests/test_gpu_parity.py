@@ -1123,6 +1123,47 @@ def test_resize_normalize_vs_oracle(dev, lib):
             assert float(canvas[i, ..., 3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("frame_hw,canvas_hw,n_items", [((72, 128), (112, 112), 37), ((576, 1024), (112, 112), 64),
+                                                         ((33, 5), (40, 24), 9), ((90, 160), (53, 37), 11),
+                                                         ((120, 200), (640, 640), 3)])
+def test_resize_tabled_kernel_is_bit_exact(dev, lib, frame_hw, canvas_hw, n_items):
+    """fp_resize_normalize's tabled kernel (csrc/image.hip resize_normalize_rows_kernel: taps of an item computed once per
+    workgroup, 8-byte window loads) against the per-pixel kernel (FP_RESIZE_PER_PIXEL=1; checked against the oracle's
+    cv2 restatement in test_resize_normalize_vs_oracle) on random crop items: up- and down-scaling, source rectangles
+    touching and crossing the frame border (clamped in the kernel), destination rectangles smaller than the canvas (pad
+    colour around them), empty destinations, source image indices out of range.  Every byte equal."""
+    import os
+    fh, fw = frame_hw
+    ch, cw = canvas_hw
+    rng = np.random.default_rng(fh * 7 + cw)
+    frames = torch.from_numpy(rng.integers(0, 256, (4, fh, fw, 3), dtype=np.uint8)).to(dev)
+    items = np.zeros((n_items, 9), np.int32)
+    for k in range(n_items):
+        sw, sh = int(rng.integers(1, fw + 1)), int(rng.integers(1, fh + 1))
+        sx, sy = int(rng.integers(-3, fw - sw + 4)), int(rng.integers(-3, fh - sh + 4))      # may stick out of the frame
+        dw, dh = int(rng.integers(0, cw + 1)), int(rng.integers(0, ch + 1))
+        dx, dy = int(rng.integers(0, cw - dw + 1)), int(rng.integers(0, ch - dh + 1))
+        items[k] = [int(rng.integers(-1, 5)), sx, sy, sw, sh, dx, dy, dw, dh]
+    items[0] = [1, 0, 0, fw, fh, 0, 0, cw, ch]              # the whole frame onto the whole canvas
+    items[1] = [2, fw - 1, fh - 1, 1, 1, 0, 0, cw, ch]      # one source pixel (the last byte of a frame row in its window)
+    it = torch.from_numpy(items).to(dev)
+    lut = torch.from_numpy(image_ref.blaze_lut()).to(dev)
+    out = {}
+    for per_pixel in (False, True):
+        if per_pixel:
+            os.environ["FP_RESIZE_PER_PIXEL"] = "1"
+        try:
+            canvas = torch.full((n_items, ch, cw, 4), float("nan"), device=dev)
+            L.check(lib.fp_resize_normalize(L.ptr(frames), 4, fh, fw, L.ptr(it), n_items, L.ptr(canvas), ch, cw, 4, L.ptr(lut),
+                                            125, 1, L.current_stream(dev)), "fp_resize_normalize")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("FP_RESIZE_PER_PIXEL", None)
+        out[per_pixel] = canvas.cpu().numpy()
+    assert np.isfinite(out[False]).all()
+    np.testing.assert_array_equal(out[False], out[True])
+
+
 def test_similarity_vs_golden_and_oracle(dev):
     """fp_l2_mean_thres / fp_l2_filter against what the reference's own get_ref_mean_vec_and_thres_from_imgs and main()
     produced (tests/golden/similarity.npz, three classes; sff/filter_faces_using_reference.py:71-100,183-197): mean to
