@@ -436,7 +436,7 @@ def run_pipeline(args):
                                        if world > 1 else "")},
             "roofline": roof, "cpu_baseline": cpu, "arithmetic": arith,
         }
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if multi:
         dist.destroy_process_group()
 
@@ -501,12 +501,31 @@ def run_c5(args):
                                                       "2.5 PF / 6) + row-max finalisation, events on torch's current stream (the "
                                                       "launch stream); the fp32-MFMA kernel (cosine_tile_kernel) ran 117 TF/s"},
                 "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if dist is not None:
         dist.destroy_process_group()
 
 
+_LINE_FD = None
+
+
+def emit_line(line):
+    """The ONE JSON line of the run, written to the process's original stdout."""
+    data = (json.dumps(line) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
+
+
 def main():
+    # Libraries write to stdout too (RCCL prints a version banner there when the process group comes up): everything but
+    # the result line goes to stderr, so that stdout carries exactly one line.
+    global _LINE_FD
+    sys.stdout.flush()
+    _LINE_FD = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 200 timed steps (~1.3 s of GPU time: long enough for a utilisation sampler to see it) after 10 warm-ups
