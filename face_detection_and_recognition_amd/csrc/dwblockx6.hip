@@ -35,6 +35,21 @@
 
 namespace {
 
+// Workgroup -> tile.  Workgroups go round-robin over the 8 XCDs (blockIdx & 7), each with its own L2: XCD x takes the
+// contiguous tile range [x T/8, (x + 1) T/8), so the bands of one image -- which share their halo rows -- run on the same
+// XCD next to each other in time and the second reader finds the rows in that L2.  FP_X6_XCD = 0: tile = blockIdx.
+#ifndef FP_X6_XCD
+#define FP_X6_XCD 1
+#endif
+__device__ __forceinline__ int x6_tile_of_block() {
+#if FP_X6_XCD
+  const int G = gridDim.x, b = blockIdx.x, q = G / 8, rr = G % 8, xcd = b & 7, k = b >> 3;
+  return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+#else
+  return blockIdx.x;
+#endif
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
+  const int tile = x6_tile_of_block();
   const int img = tile / K::NBAND;
   const int r0 = (tile % K::NBAND) * K::RB;
   const int elo = r0 > 0 ? r0 - 1 : 0;                                 // first / last computed expand row
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void dwblock_x6q_kernel(DwbX6Args p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
+  const int tile = x6_tile_of_block();
   const int img = tile / K::TPI, tq = tile % K::TPI;
   const int r0 = (tq / K::TPR) * 7, c0 = (tq % K::TPR) * 7;
   const int er0 = r0 > 0 ? r0 - 1 : 0, ec0 = c0 > 0 ? c0 - 1 : 0;     // first computed expand row / column
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(512, 1) void dwblock_x6s_kernel(DwbX6Args p) {
   const bool matrix = wave < 4;
   const int mw = wave & 3;                                                 // index inside the role
   const int l15 = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
+  const int tile = x6_tile_of_block();
   const int img = tile / K::NBAND;
   const int r0 = (tile % K::NBAND) * K::RB;
   const int elo = r0 > 0 ? r0 - 1 : 0;
@@ -991,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
+  const int tile = x6_tile_of_block();
   const int img = tile / K::NBAND;
   const int ro0 = (tile % K::NBAND) * K::RBO;                          // first output row
   const int nro = min(K::RBO, K::HO - ro0);                            // output rows of this band
