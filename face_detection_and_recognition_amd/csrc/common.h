@@ -53,6 +53,14 @@ static inline fp_divisor fp_make_divisor(unsigned d) {
 }
 __device__ __forceinline__ unsigned fp_fastdiv(unsigned n, fp_divisor d) { return __umulhi(n, d.mul) >> d.shift; }
 
+// Workgroup -> work item for 1-D grids.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx & 7), each with its own
+// L2: XCD x gets the contiguous range [x G/8, (x + 1) G/8) of items, so items next to each other -- the column chunks of one
+// row tile, the bands of one image -- run on the same XCD close in time and share their re-read operands in that L2.
+__device__ __forceinline__ unsigned fp_xcd_block() {
+  const unsigned G = gridDim.x, b = blockIdx.x, q = G >> 3, rr = G & 7u, xcd = b & 7u, k = b >> 3;
+  return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+}
+
 // A 64-bit offset the caller knows to be wave-uniform, rebuilt from readfirstlane'd halves so that the compiler keeps
 // it in SGPRs: base + offset stays a scalar address and `global_load v, v_offset32, s[addr:addr+1] offset:imm` needs no
 // 64-bit vector address arithmetic.  (Offsets, not pointers: an integer -> pointer cast loses the global address space

@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
   const int nchunk = p.N / NC;
-  const int chunk = blockIdx.x % nchunk;                 // column chunks of one row tile sit next to each other (A re-read from L2)
-  const long row0 = (long)(blockIdx.x / nchunk) * BM + wave * (MT * 16);
+  const unsigned vb = fp_xcd_block();                    // the column chunks of one row tile run on ONE XCD, next to each other: A re-read from its L2
+  const int chunk = vb % nchunk;
+  const long row0 = (long)(vb / nchunk) * BM + wave * (MT * 16);
   const int c0 = chunk * NC;
   const int KS = p.K / 32;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -271,8 +272,9 @@ __global__ __launch_bounds__(256, 2) void convx6_kernel(ConvX6Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
   const int nchunk = p.Npad / NC;
-  const int chunk = blockIdx.x % nchunk;
-  const long row0 = (long)(blockIdx.x / nchunk) * BM + wave * (MT * 16);
+  const unsigned vb = fp_xcd_block();
+  const int chunk = vb % nchunk;
+  const long row0 = (long)(vb / nchunk) * BM + wave * (MT * 16);
   const int c0 = chunk * NC;
   const int CS = (p.Cin + 31) / 32;
   const int NSL = p.KH * p.KH * CS;                      // slabs: (tap, channel slab)

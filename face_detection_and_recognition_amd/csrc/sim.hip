@@ -165,8 +165,9 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 3) void cosine_x6_kernel(const f
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
   const int nchunk = Npad / NC;
-  const int chunk = blockIdx.x % nchunk;
-  const long row0 = (long)(blockIdx.x / nchunk) * XBM + wave * (MT * 16);
+  const unsigned vb = fp_xcd_block();                    // the reference chunks of one gallery row tile on ONE XCD (gallery rows from its L2)
+  const int chunk = vb % nchunk;
+  const long row0 = (long)(vb / nchunk) * XBM + wave * (MT * 16);
   const int c0 = chunk * NC;
   const int KS = D / 32;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
