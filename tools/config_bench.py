@@ -70,9 +70,25 @@ def yolo_to_embed(dev, B=256, faces_per_frame=4.0):
     _, cand, pipe = best
     n = pipe.step(frames)["n_faces"]
     t = timeit(lambda: pipe.step(frames))
+    # the same steps software-pipelined on two streams (FacePipeline.step_overlapped: the detector of batch k + 1 beside the
+    # embedder of batch k), as bench.py runs configs[1]
+    det2 = W.build_yolo_detector(dev, calib, "yolov5s", cand_per_frame=cand)
+    pipe2 = FacePipeline(det2, emb, None, max_faces_per_frame=64, two_streams=True)
+
+    def overlapped(k):
+        for _ in range(k):
+            pipe2.step_overlapped(frames)
+        return pipe2.flush()["n_faces"]
+    n2 = overlapped(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    overlapped(10)
+    torch.cuda.synchronize()
+    t2 = (time.perf_counter() - t0) / 10
     print(json.dumps({"config": f"yolov5s-face detect -> Mobile-FaceNet 112x112, batch {B} frames", "ms": round(t * 1e3, 3),
                       "crops_per_step": n, "cand_per_frame": cand, "search": table, "frames_per_s": round(B / t, 1),
-                      "crops_per_s": round(n / t, 1)}), flush=True)
+                      "crops_per_s": round(n / t, 1), "two_stream_ms": round(t2 * 1e3, 3),
+                      "two_stream_frames_per_s": round(B / t2, 1), "two_stream_crops_per_step": n2}), flush=True)
 
 
 def embed_1024(dev):
