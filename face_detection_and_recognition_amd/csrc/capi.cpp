@@ -80,7 +80,14 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_BLAZECHAIN && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
-  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW)) return FP_ERR_INVALID_ARG;
+  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW | FP_OPF_IN_UP2)) return FP_ERR_INVALID_ARG;
+  if (op.flags & FP_OPF_IN_UP2) {
+    // channels [0, res_C) come from the res view at half resolution (facepath.h): only the split-MFMA pointwise kernel reads that
+    if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3)) return FP_ERR_INVALID_ARG;
+    if (!fp_pwx6_eligible(op) && !fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
+    const int64_t up_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)op.res_H * op.res_W - 1) * op.res_ld + op.res_C;
+    if (!span_ok(op.res_off, up_ext, arena_floats)) return FP_ERR_BOUNDS;
+  }
   if ((op.flags & FP_OPF_IN_DW) && (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3))) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW && op.kind != FP_OP_BLAZECHAIN)
     return FP_ERR_INVALID_ARG;
@@ -251,7 +258,9 @@ const char* fp_op_kernel_name(const fp_op* op) {
   switch (op->kind) {
     case FP_OP_CONV: {
       if (op->flags & FP_OPF_SPLIT3) {
-        if (fp_pwx6_eligible(*op)) snprintf(buf, sizeof(buf), "pwx6_kernel<%d, %d>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8, fp_pwx6_mt(*op));
+        if (fp_pwx6_eligible(*op))
+          snprintf(buf, sizeof(buf), "pwx6_kernel<%d, %d, %s>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8, fp_pwx6_mt(*op),
+                   (op->flags & FP_OPF_IN_UP2) ? "true" : "false");
         else snprintf(buf, sizeof(buf), "convx6_kernel<%d>", fp_convx6_nt16(*op));
         return buf;
       }

@@ -33,6 +33,11 @@ struct PwX6Args {
   const float* slope;
   long M;                    // rows = N * H * W
   int K, N, in_ld, out_ld, res_ld, res_C, act, res_mode;
+  // FP_OPF_IN_UP2: input channels [0, 32 * up_slabs) are the nearest-neighbour 2x upsampling of `up` (an H/2 x W/2 map)
+  const float* up;
+  long up_ns;
+  int up_ld, up_slabs, W2, HW;   // W2 = W / 2, HW = H * W
+  fp_divisor hw_div, w_div;  // H * W, W
 };
 
 constexpr int MT = 4;        // 16-row tiles per wave (convx6_kernel; pwx6_kernel's default)
@@ -41,7 +46,11 @@ constexpr int BM = 4 * MT * 16;
 // NT16 = 16-column tiles of a column chunk (3: N = 48, 4: N = 64, 8: chunks of 128); MT_ = 16-row tiles per wave: 4 (256-row
 // workgroup tiles, two workgroups per CU) or 2 (128-row tiles, three per CU) -- the launcher takes the small form when the
 // large one would leave the last round of workgroups mostly empty (409 600 rows = 1600 large tiles on 512 slots = 3.1 rounds)
-template <int NT16, int MT_>
+// UP: the op carries FP_OPF_IN_UP2 -- the first up_slabs K slabs of a row come from the pixel (y / 2, x / 2) of the half-size
+// map `up` (nn.Upsample(scale_factor=2, mode="nearest") + Concat of y5/models/yolo.py's head folded into the operand
+// addressing: the upsampled tensor is never written, and the small map is read from L2 four times instead of the large one
+// from HBM once).
+template <int NT16, int MT_, bool UP>
 __global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p) {
   constexpr int MT = MT_, BM = 4 * MT_ * 16;
   constexpr int NC = NT16 * 16;
@@ -82,6 +91,18 @@ __global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p)
     r = r < p.M ? r : p.M - 1;
     arow[t] = p.in + r * p.in_ld + 8 * q;
   }
+  const float* urow[UP ? MT : 1];
+  if constexpr (UP) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      long r = row0 + 16 * t + l15;
+      r = r < p.M ? r : p.M - 1;
+      const unsigned img = fp_fastdiv((unsigned)r, p.hw_div);
+      const unsigned pix = (unsigned)r - img * (unsigned)p.HW;
+      const unsigned y = fp_fastdiv(pix, p.w_div), x = pix - y * (unsigned)(2 * p.W2);
+      urow[t] = p.up + (long)img * p.up_ns + (long)((y >> 1) * p.W2 + (x >> 1)) * p.up_ld + 8 * q;
+    }
+  }
   // A slabs in flight: one ahead (large tiles: no registers for more) or two ahead (small tiles: a slab's MFMAs, 0.85 us, do not
   // cover an HBM round trip).  The slab loop is written out for two buffers so that the register arrays are indexed statically.
   constexpr int AD = MT == 2 ? 2 : 1;
@@ -89,8 +110,10 @@ __global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p)
   auto load_a = [&](int ks, int buf) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      araw[buf][t][0] = *(const f32x4*)(arow[t] + 32 * ks);
-      araw[buf][t][1] = *(const f32x4*)(arow[t] + 32 * ks + 4);
+      const float* a = arow[t];
+      if constexpr (UP) a = ks < p.up_slabs ? urow[t] : a;
+      araw[buf][t][0] = *(const f32x4*)(a + 32 * ks);
+      araw[buf][t][1] = *(const f32x4*)(a + 32 * ks + 4);
     }
   };
 
@@ -230,11 +253,21 @@ int launch(const PwX6Args& a, hipStream_t s) {
   const long nchunk = a.N / (NT16 * 16);
   const long big = (a.M + BM - 1) / BM * nchunk;
   if (2 * big >= (1L << 31)) return FP_ERR_UNSUPPORTED;
-  if (pwx6_small_tiles(a.M, (int)nchunk)) {
+  const bool up = a.up != nullptr;
+  // (the large-tile form with the second set of row pointers of an FP_OPF_IN_UP2 op needs 257 registers at 128-column chunks)
+  if (pwx6_small_tiles(a.M, (int)nchunk) || (up && NT16 == 8)) {
     const long tiles = (a.M + BM / 2 - 1) / (BM / 2) * nchunk;
-    hipLaunchKernelGGL((pwx6_kernel<NT16, 2>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+    if (up) hipLaunchKernelGGL((pwx6_kernel<NT16, 2, true>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((pwx6_kernel<NT16, 2, false>), dim3((unsigned)tiles), dim3(256), lds, s, a);
   } else {
-    hipLaunchKernelGGL((pwx6_kernel<NT16, 4>), dim3((unsigned)big), dim3(256), lds, s, a);
+    if constexpr (NT16 != 8) {
+      if (up) {
+        hipLaunchKernelGGL((pwx6_kernel<NT16, 4, true>), dim3((unsigned)big), dim3(256), lds, s, a);
+        FP_CHECK_LAUNCH();
+        return FP_OK;
+      }
+    }
+    hipLaunchKernelGGL((pwx6_kernel<NT16, 4, false>), dim3((unsigned)big), dim3(256), lds, s, a);
   }
   FP_CHECK_LAUNCH();
   return FP_OK;
@@ -259,6 +292,11 @@ struct ConvX6Args {
   int H, W, OH, OW, Cin, Cout, Npad, KH, stride, pad;
   int in_ld, out_ld, res_ld, res_C, act, res_mode;
   long in_ns;
+  // FP_OPF_IN_UP2 (1x1 only): channels [0, up_C) of input pixel (y, x) come from pixel (y / 2, x / 2) of `up` (up_C % 8 == 0:
+  // a lane's eight channels come from one of the two tensors)
+  const float* up;
+  long up_ns;
+  int up_ld, up_C, W2;
   fp_divisor div_ohw, div_ow;
 };
 
@@ -319,6 +357,8 @@ __global__ __launch_bounds__(256, 2) void convx6_kernel(ConvX6Args p) {
       const int iy = (iyx[t] >> 16) + dy, ix = (int)(short)(iyx[t] & 0xffff) + dx;
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const float* src = p.in + ((long)nimg[t] * p.in_ns + (long)((iy * p.W + ix) * p.in_ld + k0));
+      if (p.up && k0 < p.up_C)           // the folded nn.Upsample: this lane's channels live in the half-size map
+        src = p.up + ((long)nimg[t] * p.up_ns + (long)(((iy >> 1) * p.W2 + (ix >> 1)) * p.up_ld + k0));
       araw[t][0] = ok && k_lo ? *(const f32x4*)src : z;
       araw[t][1] = ok && k_hi ? *(const f32x4*)(src + 4) : z;
     }
@@ -437,8 +477,16 @@ int chunk_tiles(int N) { return N == 48 ? 3 : N == 64 ? 4 : (N % 128 == 0 ? 8 : 
 // A CONV that carries FP_OPF_SPLIT3: pointwise on dense rows, K a multiple of 32 (>= 64), Cout 48 / 64 / a multiple of 128,
 // 16-byte aligned views, residual modes none / add before / add after / ShuffleV2 interleave.
 bool fp_pwx6_eligible(const fp_op& op) {
-  if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3) || (op.flags & ~FP_OPF_SPLIT3)) return false;
+  if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3) || (op.flags & ~(FP_OPF_SPLIT3 | FP_OPF_IN_UP2))) return false;
   if (op.KH != 1 || op.KW != 1 || op.stride != 1 || op.pad_t || op.pad_l || op.OH != op.H || op.OW != op.W) return false;
+  if (op.flags & FP_OPF_IN_UP2) {
+    // channels [0, res_C) of the input = the res view (H/2 x W/2, dense rows) upsampled 2x; no residual on such an op
+    if (op.res_mode != FP_RES_NONE || op.res_C % 32 || op.res_C <= 0 || op.res_C >= op.Cin) return false;
+    if (op.H % 2 || op.W % 2 || op.res_H != op.H / 2 || op.res_W != op.W / 2 || op.W < 2 || (long)op.H * op.W < 2) return false;
+    if (op.res_ld % 4 || op.res_off % 4 || op.res_ns % 4 || op.res_ld < op.res_C || op.res_ns < (long)op.res_H * op.res_W * op.res_ld)
+      return false;
+    if ((long)op.N * op.H * op.W >= (1L << 31)) return false;
+  }
   if (op.Cin % 32 || op.Cin < 64 || chunk_tiles(op.Cout) == 0 || op.out_cmul != 1) return false;
   const long HW = (long)op.H * op.W;
   if (op.in_ns != HW * op.in_ld || op.out_ns != HW * op.out_ld) return false;
@@ -458,6 +506,7 @@ long fp_pwx6_w_floats(const fp_op& op) { return (long)op.Cin * op.Cout * 3 / 2; 
 // 16-row tiles per wave the launcher will pick for this op at its current batch (kernel-name reporting)
 int fp_pwx6_mt(const fp_op& op) {
   const int nt = chunk_tiles(op.Cout);
+  if (nt == 8 && (op.flags & FP_OPF_IN_UP2)) return 2;
   return nt && pwx6_small_tiles((long)op.N * op.H * op.W, op.Cout / (nt * 16)) ? 2 : 4;
 }
 
@@ -481,6 +530,16 @@ int fp_launch_pwx6(const fp_op& op, const float* weights, float* arena, hipStrea
   a.res_C = op.res_C;
   a.act = op.act;
   a.res_mode = op.res_mode;
+  if (op.flags & FP_OPF_IN_UP2) {
+    a.up = arena + op.res_off;
+    a.up_ns = op.res_ns;
+    a.up_ld = op.res_ld;
+    a.up_slabs = op.res_C / 32;
+    a.W2 = op.W / 2;
+    a.HW = op.H * op.W;
+    a.hw_div = fp_make_divisor((unsigned)a.HW);
+    a.w_div = fp_make_divisor((unsigned)op.W);
+  }
   switch (chunk_tiles(op.Cout)) {
     case 3: return launch<3>(a, s);
     case 4: return launch<4>(a, s);
@@ -497,7 +556,13 @@ static bool convx6_shape(const fp_op& op) {
 }
 
 bool fp_convx6_eligible(const fp_op& op) {
-  if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3) || (op.flags & ~FP_OPF_SPLIT3)) return false;
+  if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3) || (op.flags & ~(FP_OPF_SPLIT3 | FP_OPF_IN_UP2))) return false;
+  if (op.flags & FP_OPF_IN_UP2) {
+    if (op.KH != 1 || op.res_mode != FP_RES_NONE || op.res_C % 8 || op.res_C <= 0 || op.res_C >= op.Cin) return false;
+    if (op.H % 2 || op.W % 2 || op.res_H != op.H / 2 || op.res_W != op.W / 2) return false;
+    if (op.res_ld % 4 || op.res_off % 4 || op.res_ns % 4 || op.res_ld < op.res_C || op.res_ns < (long)op.res_H * op.res_W * op.res_ld)
+      return false;
+  }
   if (!convx6_shape(op) || op.Cin % 4 || op.Cin < 32 || op.Cout % 4 || op.Cout < 32 || op.out_cmul != 1) return false;
   const long OHW = (long)op.OH * op.OW;
   if (op.in_ns < (long)op.H * op.W * op.in_ld || op.out_ns != OHW * op.out_ld) return false;
@@ -543,6 +608,13 @@ int fp_launch_convx6(const fp_op& op, const float* weights, float* arena, hipStr
   a.in_ns = op.in_ns;
   a.div_ohw = fp_make_divisor((unsigned)(op.OH * op.OW));
   a.div_ow = fp_make_divisor((unsigned)op.OW);
+  if (op.flags & FP_OPF_IN_UP2) {
+    a.up = arena + op.res_off;
+    a.up_ns = op.res_ns;
+    a.up_ld = op.res_ld;
+    a.up_C = op.res_C;
+    a.W2 = op.W / 2;
+  }
   int nt16;
   general_tiles(op.Cout, &nt16, &a.Npad);
   switch (nt16) {

@@ -450,6 +450,7 @@ class Model(nn.Module):
 
     # ---- plan ----
     CONCAT_IN_PLACE = True   # class-wide switch: False copies every Concat input (A/B parity tests)
+    FOLD_UPSAMPLE = True     # class-wide switch: False launches upsample2x_kernel in front of every Concat (A/B parity tests)
 
     FUSE_LETTERBOX = True    # class-wide switch: False keeps the stand-alone letterbox kernel (A/B parity tests)
 
@@ -489,6 +490,18 @@ class Model(nn.Module):
                                                                               Upsample)):
                             place[src] = (m.i, pos)
         cat_bufs = {}     # concat layer index -> Buf
+        # nn.Upsample in front of a Concat (first input) whose readers are pointwise convs on the split-MFMA kernel: the
+        # upsampled slice is never written, the readers take those channels from the half-size map (FP_OPF_IN_UP2).
+        # fold[concat layer] = the half-size view; its producer then lives as long as the Concat's output does.
+        fold = {}
+        fold_src = {}     # Upsample layer index -> concat layer index
+        if Model.CONCAT_IN_PLACE and Model.FOLD_UPSAMPLE and PlanBuilder.X6 and PlanBuilder.UP2_FOLD:
+            for m in layers:
+                if isinstance(m, Upsample) and place.get(m.i, (None, None))[1] == 0 and srcs(m)[0] >= 0:
+                    cat_i = place[m.i][0]
+                    fold_src[m.i] = cat_i
+                    s0 = srcs(m)[0]
+                    last_use[s0] = max(last_use.get(s0, s0), last_use.get(cat_i, cat_i))
 
         outs = {}
         heads = []
@@ -521,7 +534,11 @@ class Model(nn.Module):
                     cb = cat_bufs[cat_i]
                     target = View(cb, sum(cb.widths[:pos]), c_self)
             xin = ins if isinstance(m, Concat) else ins[0]
-            if isinstance(m, nn.Sequential):
+            if m.i in fold_src and target is not None and m.i in place:
+                # folded Upsample: nothing is launched; the Concat's output will carry the half-size view
+                fold[fold_src[m.i]] = xin
+                y = target
+            elif isinstance(m, nn.Sequential):
                 y = xin
                 for k, sub in enumerate(m):
                     y2 = sub.emit(pb, y, out=target) if (target is not None and k == len(m) - 1) else sub.emit(pb, y)
@@ -532,6 +549,9 @@ class Model(nn.Module):
                 y = m.emit(pb, None, out=target, u8=(H, W, frame_hw[0], frame_hw[1], 0))
             else:
                 y = m.emit(pb, xin, out=target) if target is not None else m.emit(pb, xin)
+            if isinstance(m, Concat) and m.i in fold:
+                assert y.buf is cat_bufs[m.i] and y.coff == 0
+                y.up = fold[m.i]
             outs[m.i] = y
             for j, lu in last_use.items():
                 if lu == m.i and j in outs and not any(outs[j].buf is cb for cb in cat_bufs.values()):

@@ -57,6 +57,9 @@ class View:
     coff: int
     C: int
     cmul: int = 1
+    up: object = None   # a View of a half-size map: channels [0, up.C) of THIS view are its nearest-neighbour 2x upsampling and
+                        # have NOT been written (PlanBuilder.conv folds them into the operand addressing, FP_OPF_IN_UP2, or
+                        # materialises them first: PlanBuilder.materialise_up)
 
     @property
     def H(self):
@@ -229,6 +232,8 @@ class PlanBuilder:
 
     # ---- op emission ----
     def _base(self, kind, x, out, OH, OW):
+        if x.up is not None and kind != L.OP_CONV:      # only conv() knows how to read a folded upsample
+            self.materialise_up(x)
         op = L.FpOp()
         op.kind = kind
         op.N = self.N
@@ -316,18 +321,44 @@ class PlanBuilder:
             return False
         return True
 
+    UP2_FOLD = os.environ.get("FP_UP2_FOLD", "1") == "1"   # nn.Upsample + Concat in front of a pointwise conv as operand addressing
+
+    def up2_ok(self, x, out, kh, kw, stride, pad, res_mode):
+        """Mirror of the FP_OPF_IN_UP2 clauses of fp_pwx6_eligible / fp_convx6_eligible (csrc/pwx6.hip): x.up can be read in
+        place of the upsampled slice."""
+        u = x.up
+        return (self.UP2_FOLD and u is not None and res_mode == L.RES_NONE and (kh, kw, stride) == (1, 1, 1) and
+                tuple(pad) == (0, 0) and u.C % 8 == 0 and 0 < u.C < x.C and u.cmul == 1 and
+                x.H % 2 == 0 and x.W % 2 == 0 and (u.H, u.W) == (x.H // 2, x.W // 2) and not u.buf.rowpad and
+                u.buf.ld % 4 == 0 and (u.buf.off + u.coff) % 4 == 0 and u.buf.ns % 4 == 0 and
+                u.buf.ns >= u.H * u.W * u.buf.ld and self.pwx6_ok(x, out, kh, kw, stride, pad, None, res_mode))
+
+    def materialise_up(self, x):
+        """Write the upsampled slice of a view that still carries `up` (a consumer that cannot fold it)."""
+        if x.up is not None:
+            u, x.up = x.up, None
+            self.upsample2x(u, View(x.buf, x.coff, u.C))
+
     def conv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None,
              act=L.ACT_NONE, res=None, res_mode=L.RES_NONE, n_convs=1):
         """Dense conv (OIHW weight); out is a View whose C >= Cout (extra channels get zeros)."""
         cout, cin, kh, kw = w.shape
         assert cin <= x.C, (cin, x.C)
         OH, OW = out.H, out.W
+        fold = x.up is not None and self.up2_ok(x, out, kh, kw, stride, pad, res_mode)
+        if x.up is not None and not fold:
+            self.materialise_up(x)
         op = self._base(L.OP_CONV, x, out, OH, OW)
         op.Cout = out.C
         op.KH, op.KW, op.stride = kh, kw, stride
         op.pad_t, op.pad_l = pad
         op.act, op.res_mode = act, res_mode
-        if self.pwx6_ok(x, out, kh, kw, stride, pad, res, res_mode) and not op.flags:
+        if fold:
+            u = x.up
+            op.flags |= L.OPF_IN_UP2
+            op.res_ld, op.res_ns, op.res_off = u.buf.ld, u.buf.ns, u.buf.off + u.coff
+            op.res_C, op.res_H, op.res_W = u.C, u.H, u.W
+        if self.pwx6_ok(x, out, kh, kw, stride, pad, res, res_mode) and not (op.flags & ~L.OPF_IN_UP2):
             # three bf16 planes [tap * CS + cs][3][Npad][32] (include/facepath.h, FP_OPF_SPLIT3 on FP_OP_CONV): K runs
             # over (tap, 32-channel slab), zero rows / columns in the padding of Cin to 32 and Cout to whole chunks
             cs = (x.C + 31) // 32
@@ -903,6 +934,8 @@ class CompiledPlan:
             b_in = op.res_H * op.res_W * 3                       # u8 frame
         else:
             b_in = op.H * op.W * op.Cin * 4
+            if op.flags & L.OPF_IN_UP2:                          # the leading res_C channels come from the half-size map
+                b_in = op.H * op.W * (op.Cin - op.res_C) * 4 + op.res_H * op.res_W * op.res_C * 4
         cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_BLAZECHAIN, L.OP_YSTEM, L.OP_YSTEM_U8,
                                 L.OP_STEM_U8) else op.Cin
         oh, ow = (op.H, op.W) if k in (L.OP_COPY, L.OP_L2NORM) else (op.OH, op.OW)

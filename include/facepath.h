@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 6
+#define FP_ABI_VERSION 7
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -170,6 +170,16 @@ typedef struct fp_op {
  *                prologue from an LDS image of the input rows and never goes to memory.
  */
 #define FP_OPF_IN_DW 16
+/*
+ * FP_OPF_IN_UP2 (ABI 7) : a pointwise (1x1) FP_OP_CONV on the split-MFMA kernels (FP_OPF_SPLIT3) whose input is
+ *                cat(upsample2x_nearest(u), v) -- nn.Upsample + Concat in front of a C3 in YOLOv5-face's head
+ *                (y5/models/yolo.py:177-198, common.py:235-242): channels [0, res_C) of pixel (y, x) are read from pixel
+ *                (y / 2, x / 2) of the res view (res_H = H / 2, res_W = W / 2, res_C a multiple of 8, res_ld, res_ns,
+ *                res_off as for a residual; res_mode must be FP_RES_NONE), channels [res_C, Cin) from the in view as
+ *                usual (in_off is the address of channel 0 of the concatenated row; its first res_C floats are never
+ *                read).  The upsampled tensor does not exist.
+ */
+#define FP_OPF_IN_UP2 32
 
 /*
  * Weight blob layouts (packed by the host side, see
@@ -226,7 +236,7 @@ typedef struct fp_op {
  *            [1280 floats: [9][96] depthwise taps (ky*3 + kx), [96] depthwise bias, [96] 1x1 bias, 224 pad] followed by
  *            three slabs (k = 32 s .. 32 s + 31) of [3 planes][96 output channels][32 k] bf16 (13 824 floats).
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -715,6 +715,72 @@ def test_dwblock_x6_stride2_vs_oracle(dev, cin, cout, groups, hw, n):
     assert np.abs(got - ref64).max() <= 2.0 * np.abs(ref - ref64).max() + 1e-6
 
 
+@pytest.mark.parametrize("hw,cu,cs,cout,n", [
+    ((40, 40), 128, 256, 128, 3),     # YOLOv5n-face head, first Concat: 128 upsampled + 256 skip channels -> merged cv1 | cv2
+    ((80, 80), 128, 128, 128, 2),     # second Concat (the 128-column chunk: small tiles forced)
+    ((20, 20), 64, 64, 64, 5),        # yolov5n-0.5 widths: one 64-column chunk
+    ((12, 10), 32, 96, 48, 7),        # non-square map, rows not a multiple of the tile, three 16-column tiles
+    ((40, 40), 128, 128, 256, 2),     # two column chunks per row tile
+    ((40, 40), 184, 184, 184, 2),     # yolov5s' widths: convx6_kernel, the boundary between the two tensors inside a 32-channel slab
+    ((80, 80), 96, 96, 96, 2),        # ... and on a slab boundary
+    ((20, 22), 40, 24, 96, 3),        # 64 input channels in two slabs, the tensor boundary at channel 40
+])
+def test_pwx6_upsample_folded_into_conv_is_bit_exact(dev, hw, cu, cs, cout, n):
+    """FP_OPF_IN_UP2 (csrc/pwx6.hip pwx6_kernel<.., true>): a pointwise conv whose input is cat(upsample2x(u), v) reading
+    the first channels from the half-size map -- nn.Upsample(None, 2, "nearest") + Concat of YOLOv5-face's head
+    (y5/models/yolo.py:177-198, common.py:235-242) as operand addressing -- against the same plan with the upsampled
+    slice materialised by upsample2x_kernel (bit-identical: same values in the same order) and against torch
+    (interpolate + cat + conv2d + SiLU on the CPU).  The slice that is never written holds NaN in the folded plan."""
+    H, W = hw
+    rng = np.random.default_rng(H * 3 + cu + cout)
+    u = rng.normal(0, 1, (n, cu, H // 2, W // 2)).astype(np.float32)
+    v = rng.normal(0, 1, (n, cs, H, W)).astype(np.float32)
+    w = rng.normal(0, (2.0 / (cu + cs)) ** 0.5, (cout, cu + cs, 1, 1)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    bias = rng.normal(0, 0.2, cout).astype(np.float32)
+    got = {}
+    for fold in (True, False):
+        old = PlanBuilder.UP2_FOLD
+        PlanBuilder.UP2_FOLD = fold
+        try:
+            pb = PlanBuilder(n)
+            ub = pb.new_buf(H // 2, W // 2, cu)
+            cb = pb.new_buf(H, W, cu + cs)
+            ob = pb.new_buf(H, W, cout)
+            x = cb.view()
+            x.up = ub.view()
+            pb.conv(x, w, ob.view(), scale=scale, bias=bias, act=L.ACT_SILU)
+            assert x.up is None or fold
+        finally:
+            PlanBuilder.UP2_FOLD = old
+        plan = CompiledPlan(pb, dev)
+        names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+        pw = cout in (48, 64) or cout % 128 == 0          # pwx6_kernel's widths (and cu + cs a multiple of 32); else convx6_kernel
+        if fold:
+            assert len(names) == 1 and plan.ops[0].flags & L.OPF_IN_UP2, names
+            assert names[0].startswith("pwx6_kernel") and names[0].endswith("true>") if pw else names[0].startswith("convx6_kernel"), names
+        else:
+            assert names[0] == "upsample2x_kernel" and not plan.ops[1].flags & L.OPF_IN_UP2, names
+            assert names[1].startswith("pwx6_kernel") and names[1].endswith("false>") if pw else names[1].startswith("convx6_kernel"), names
+        plan.buf_tensor(ub, n).copy_(torch.from_numpy(u).to(dev).permute(0, 2, 3, 1))
+        ct = plan.buf_tensor(cb, n)
+        ct[..., :cu].fill_(float("nan"))
+        ct[..., cu:].copy_(torch.from_numpy(v).to(dev).permute(0, 2, 3, 1))
+        ot = plan.buf_tensor(ob, n)
+        ot.fill_(float("nan"))
+        plan.run()
+        torch.cuda.synchronize()
+        got[fold] = ot.permute(0, 3, 1, 2).cpu().numpy()
+        if fold:
+            assert bool(torch.isnan(ct[..., :cu]).all())          # the folded plan never wrote the slice
+    assert np.isfinite(got[True]).all()
+    np.testing.assert_array_equal(got[True], got[False])
+    xs = torch.cat([F.interpolate(torch.from_numpy(u), scale_factor=2, mode="nearest"), torch.from_numpy(v)], 1)
+    r = F.conv2d(xs, torch.from_numpy(w)) * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(bias).view(1, -1, 1, 1)
+    r = (r * torch.sigmoid(r)).numpy()
+    assert rel_err(got[True], r) < 1e-5
+
+
 @pytest.mark.parametrize("k,n,act,res_mode,shape,in_slice", [
     (128, 128, "silu", "none", (3, 20, 20), 0),        # ragged row tile (1200 rows), one chunk
     (256, 128, "silu", "none", (2, 40, 40), 128),      # input = channel slice [128, 384) of a 384-channel concat buffer

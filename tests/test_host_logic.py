@@ -300,3 +300,48 @@ def test_split3_plan_layouts_and_validation():
     assert all(v == 0 for k, v in counts.items() if not k[2])
     assert counts[("MobileFaceNet", "", True)] == 17          # 15 Depth_Wise blocks + conv_6_sep + the Linear
     assert all(v > 0 for k, v in counts.items() if k[2])
+
+
+def test_upsample_fold_plan_and_validation(lib):
+    """FP_OPF_IN_UP2 (include/facepath.h): YOLOv5n-face's two Upsample + Concat pairs become operand addressing of the C3's
+    merged cv1 | cv2 conv (no upsample2x op; the half-size map outlives the Concat), yolov5s' on the general split kernel;
+    the validator rejects the flag where nothing can honour it and views that leave the arena."""
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model
+    pb = Model("yolov5n")._emit(2, 640, 640, None)[0]
+    ops, weights, arena = pb.finish()
+    names = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops]
+    up = [i for i, op in enumerate(ops) if op.flags & L.OPF_IN_UP2]
+    assert len(up) == 2 and "upsample2x_kernel" not in names and all(names[i].endswith("true>") for i in up)
+    for i in up:
+        op = ops[i]
+        assert (op.res_H, op.res_W) == (op.H // 2, op.W // 2) and op.res_C == 128 and op.res_mode == L.RES_NONE
+        # nobody overwrites the half-size map between its producer and this reader
+        lo, hi = op.res_off, op.res_off + (op.N - 1) * op.res_ns + (op.res_H * op.res_W - 1) * op.res_ld + op.res_C
+        prod = max(j for j in range(i) if ops[j].out_off == op.res_off)
+        for j in range(prod + 1, i):
+            o = ops[j]
+            oh, ow = (o.H, o.W) if o.kind in (L.OP_COPY, L.OP_L2NORM) else (o.OH, o.OW)
+            assert o.out_off >= hi or o.out_off + (o.N - 1) * o.out_ns + (oh * ow - 1) * o.out_ld + o.out_ld <= lo, (i, j)
+    arr = (L.FpOp * len(ops))(*ops)
+    assert lib.fp_plan_validate(arr, len(ops), weights.size, arena) == 0
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[up[0]].res_off = arena - 8                      # the half-size view would leave the arena
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[up[0]].res_H += 1                               # not the half-size map of this op's input
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
+    bad = (L.FpOp * len(ops))(*ops)
+    k = next(i for i, op in enumerate(ops) if op.kind == L.OP_DWCONV)
+    bad[k].flags |= L.OPF_IN_UP2                        # only the split pointwise conv reads a folded upsample
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -1
+    ops_s = Model("yolov5s")._emit(2, 640, 640, None)[0].finish()[0]      # widths 184 / 96: the general split kernel reads the fold
+    names_s = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops_s]
+    ups = [i for i, op in enumerate(ops_s) if op.flags & L.OPF_IN_UP2]
+    assert "upsample2x_kernel" not in names_s and sorted(ops_s[i].res_C for i in ups) == [96, 184]
+    assert all(names_s[i].startswith("convx6_kernel") for i in ups)
+    Model.FOLD_UPSAMPLE = False
+    try:
+        names_u = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in Model("yolov5n")._emit(2, 640, 640, None)[0].finish()[0]]
+    finally:
+        Model.FOLD_UPSAMPLE = True
+    assert names_u.count("upsample2x_kernel") == 2 and not any(n.endswith("true>") and n.startswith("pwx6") for n in names_u)
