@@ -14,6 +14,7 @@
 //   * operands swapped (D^T = W^T A^T): a lane ends up with 4 consecutive channels of ONE pixel -- 16-byte epilogue
 //     (scale / bias, residual, ReLU / PReLU / SiLU, ShuffleV2's interleaved store) straight from the accumulators.
 // Eligibility (fp_pwx6_eligible) mirrors plan.py's PlanBuilder.pwx6_ok: the op carries FP_OPF_SPLIT3 and split weights.
+#include <stdlib.h>
 #include <string.h>
 
 #include "split.h"
@@ -241,6 +242,17 @@ __global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p)
 }
 
 // rounds of workgroups the large tiles need (512 slots): below 8, and with a last round less than 70 % full -> small tiles
+// K at or below which the small tiles are taken regardless of the round count (0 = never): with two or four K slabs a tile is
+// one HBM round trip + its MFMAs, and three co-resident workgroups with every slab of A in flight hide more of it than two.
+static int pwx6_small_maxk() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FP_PWX6_SMALL_MAXK");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 bool pwx6_small_tiles(long M, int nchunk) {
   const double rounds = (double)((M + BM - 1) / BM * nchunk) / 512.0;
   const double frac = rounds - (double)(long)rounds;
@@ -255,7 +267,7 @@ int launch(const PwX6Args& a, hipStream_t s) {
   if (2 * big >= (1L << 31)) return FP_ERR_UNSUPPORTED;
   const bool up = a.up != nullptr;
   // (the large-tile form with the second set of row pointers of an FP_OPF_IN_UP2 op needs 257 registers at 128-column chunks)
-  if (pwx6_small_tiles(a.M, (int)nchunk) || (up && NT16 == 8)) {
+  if (pwx6_small_tiles(a.M, (int)nchunk) || (up && NT16 == 8) || a.K <= pwx6_small_maxk()) {
     const long tiles = (a.M + BM / 2 - 1) / (BM / 2) * nchunk;
     if (up) hipLaunchKernelGGL((pwx6_kernel<NT16, 2, true>), dim3((unsigned)tiles), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((pwx6_kernel<NT16, 2, false>), dim3((unsigned)tiles), dim3(256), lds, s, a);
@@ -506,7 +518,7 @@ long fp_pwx6_w_floats(const fp_op& op) { return (long)op.Cin * op.Cout * 3 / 2; 
 // 16-row tiles per wave the launcher will pick for this op at its current batch (kernel-name reporting)
 int fp_pwx6_mt(const fp_op& op) {
   const int nt = chunk_tiles(op.Cout);
-  if (nt == 8 && (op.flags & FP_OPF_IN_UP2)) return 2;
+  if ((nt == 8 && (op.flags & FP_OPF_IN_UP2)) || op.Cin <= pwx6_small_maxk()) return 2;
   return nt && pwx6_small_tiles((long)op.N * op.H * op.W, op.Cout / (nt * 16)) ? 2 : 4;
 }
 
