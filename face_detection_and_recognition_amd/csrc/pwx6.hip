@@ -309,6 +309,10 @@ struct ConvX6Args {
   const float* up;
   long up_ns;
   int up_ld, up_C, W2;
+  // flat: Cin < 32 (a multiple of 8): K runs over the flattened (tap, channel) index in slabs of 32 -- two taps of a 16-channel
+  // input per slab (YOLOv5n-face's stem_2b, 3x3 stride 2 on 16 channels: K = 144 in 5 slabs instead of 9 half-empty ones)
+  int flat;
+  fp_divisor div_cin;
   fp_divisor div_ohw, div_ow;
 };
 
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void convx6_kernel(ConvX6Args p) {
   const long row0 = (long)(vb / nchunk) * BM + wave * (MT * 16);
   const int c0 = chunk * NC;
   const int CS = (p.Cin + 31) / 32;
-  const int NSL = p.KH * p.KH * CS;                      // slabs: (tap, channel slab)
+  const int NSL = p.flat ? (p.KH * p.KH * p.Cin + 31) / 32 : p.KH * p.KH * CS;   // slabs: (tap, channel slab), or 32 flattened k
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int sl) {
@@ -360,10 +364,22 @@ __global__ __launch_bounds__(256, 2) void convx6_kernel(ConvX6Args p) {
   }
   f32x4 araw[MT][2];
   auto load_a = [&](int sl) {
-    const int tap = sl / CS, cs = sl - tap * CS;
-    const int dy = tap / p.KH, dx = tap - dy * p.KH;
-    const int k0 = 32 * cs + 8 * q;
-    const bool k_lo = k0 < p.Cin, k_hi = k0 + 4 < p.Cin;
+    int tap, cs, k0;
+    bool k_lo, k_hi;
+    if (p.flat) {                      // per-lane tap: this lane's eight k are channels k0 .. k0 + 7 of tap (32 sl + 8 q) / Cin
+      const unsigned kf = 32u * sl + 8u * q;
+      tap = (int)fp_fastdiv(kf, p.div_cin);
+      k0 = (int)kf - tap * p.Cin;
+      cs = 0;
+      k_lo = k_hi = tap < p.KH * p.KH;
+    } else {
+      tap = sl / CS;
+      cs = sl - tap * CS;
+      k0 = 32 * cs + 8 * q;
+      k_lo = k0 < p.Cin;
+      k_hi = k0 + 4 < p.Cin;
+    }
+    const int dy = (tap >= p.KH) + (tap >= 2 * p.KH), dx = tap - dy * p.KH;     // KH in {1, 3}
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int iy = (iyx[t] >> 16) + dy, ix = (int)(short)(iyx[t] & 0xffff) + dx;
@@ -471,7 +487,8 @@ int launch_conv(const ConvX6Args& a, hipStream_t s) {
 void general_tiles(int cout, int* nt16, int* npad) {
   const int nt = (cout + 15) / 16;
   int per;
-  if (nt <= 3) per = 3;
+  if (nt <= 2) per = 2;
+  else if (nt <= 3) per = 3;
   else if (nt <= 4) per = 4;
   else if (nt <= 6) per = 6;
   else {   // chunks of 6 or 4 tiles, whichever pads less (8-tile chunks leave convx6_kernel no registers for its addressing)
@@ -575,7 +592,9 @@ bool fp_convx6_eligible(const fp_op& op) {
     if (op.res_ld % 4 || op.res_off % 4 || op.res_ns % 4 || op.res_ld < op.res_C || op.res_ns < (long)op.res_H * op.res_W * op.res_ld)
       return false;
   }
-  if (!convx6_shape(op) || op.Cin % 4 || op.Cin < 32 || op.Cout % 4 || op.Cout < 32 || op.out_cmul != 1) return false;
+  // Cin >= 32, or 8 / 16 / 24 channels under a 3x3 (K flattened over taps and channels)
+  const bool flat = op.Cin < 32 && op.KH == 3 && op.Cin % 8 == 0 && op.Cin >= 8 && !(op.flags & FP_OPF_IN_UP2);
+  if (!convx6_shape(op) || op.Cin % 4 || (op.Cin < 32 && !flat) || op.Cout % 4 || op.Cout < 32 || op.out_cmul != 1) return false;
   const long OHW = (long)op.OH * op.OW;
   if (op.in_ns < (long)op.H * op.W * op.in_ld || op.out_ns != OHW * op.out_ld) return false;
   if (op.in_ld % 4 || op.in_off % 4 || op.in_ns % 4 || op.out_ld % 4 || op.out_off % 4 || op.w_off % 4) return false;
@@ -599,7 +618,8 @@ int fp_convx6_nt16(const fp_op& op) {
 long fp_convx6_w_floats(const fp_op& op) {
   int nt16, npad;
   general_tiles(op.Cout, &nt16, &npad);
-  return (long)op.KH * op.KW * ((op.Cin + 31) / 32) * 3 * npad * 32 / 2;
+  const long slabs = op.Cin < 32 ? ((long)op.KH * op.KW * op.Cin + 31) / 32 : (long)op.KH * op.KW * ((op.Cin + 31) / 32);
+  return slabs * 3 * npad * 32 / 2;
 }
 
 int fp_launch_convx6(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
@@ -620,6 +640,8 @@ int fp_launch_convx6(const fp_op& op, const float* weights, float* arena, hipStr
   a.in_ns = op.in_ns;
   a.div_ohw = fp_make_divisor((unsigned)(op.OH * op.OW));
   a.div_ow = fp_make_divisor((unsigned)op.OW);
+  a.flat = op.Cin < 32;
+  a.div_cin = fp_make_divisor((unsigned)(op.Cin >= 2 ? op.Cin : 2));
   if (op.flags & FP_OPF_IN_UP2) {
     a.up = arena + op.res_off;
     a.up_ns = op.res_ns;
@@ -630,6 +652,7 @@ int fp_launch_convx6(const fp_op& op, const float* weights, float* arena, hipStr
   int nt16;
   general_tiles(op.Cout, &nt16, &a.Npad);
   switch (nt16) {
+    case 2: return launch_conv<2>(a, s);
     case 3: return launch_conv<3>(a, s);
     case 4: return launch_conv<4>(a, s);
     default: return launch_conv<6>(a, s);

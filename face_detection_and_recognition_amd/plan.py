@@ -271,11 +271,17 @@ class PlanBuilder:
     X6_SMALL_K_MIN_PIXELS = 400   # below 128 input channels only on maps of at least 20 x 20 (measured on YOLOv5-face; the
                                   # small-map 1x1 convs of BlazeFace stay on the fp32-MFMA kernels)
 
+    # 3x3 convs on 8 / 16 / 24 input channels on the split kernel with K flattened over (tap, channel) (YOLOv5n-face's stem_2b,
+    # 16 -> 32 stride 2 at 320x320: 945 us on conv_igemm_kernel)
+    CONV3_X6_FLAT = os.environ.get("FP_CONV3_X6_FLAT", "1") == "1"
+
     @staticmethod
     def x6_tiles(cout):
         """(16-column tiles per chunk, padded width) -- mirror of general_tiles (csrc/pwx6.hip)."""
         nt = (cout + 15) // 16
-        if nt <= 3:
+        if nt <= 2:
+            per = 2
+        elif nt <= 3:
             per = 3
         elif nt <= 4:
             per = 4
@@ -298,14 +304,15 @@ class PlanBuilder:
             if not cls.PW_X6_MIN_K or x.C < cls.PW_X6_MIN_K:
                 return False
         elif k3:
-            if not cls.CONV3_X6_MIN_K or x.C < cls.CONV3_X6_MIN_K:
+            flat = cls.CONV3_X6_FLAT and x.C in (8, 16, 24)      # K flattened over (tap, channel): csrc/pwx6.hip convx6_kernel
+            if not cls.CONV3_X6_MIN_K or (x.C < cls.CONV3_X6_MIN_K and not flat):
                 return False
         else:
             return False
         if x.C < 128 and out.H * out.W < cls.X6_SMALL_K_MIN_PIXELS:
             return False
         fast = k1 and x.C % 32 == 0 and (out.C in (48, 64) or out.C % 128 == 0) and x.buf.ns == x.H * x.W * x.buf.ld
-        if x.C % 4 or out.C % 4 or out.C < 48 or (not fast and (out.H * out.W < 2 or out.W < 2)):   # (32 outputs: a third of the three-tile chunk would be padding)
+        if x.C % 4 or out.C % 4 or out.C < (32 if k3 and x.C < 32 else 48) or (not fast and (out.H * out.W < 2 or out.W < 2)):   # (32 outputs: a third of the three-tile chunk would be padding)
             return False
         ohw = out.H * out.W
         if x.buf.ns < x.H * x.W * x.buf.ld or x.buf.ns % 4 or x.buf.ld % 4 or (x.buf.off + x.coff) % 4:
@@ -363,9 +370,17 @@ class PlanBuilder:
             # over (tap, 32-channel slab), zero rows / columns in the padding of Cin to 32 and Cout to whole chunks
             cs = (x.C + 31) // 32
             npad = self.x6_tiles(out.C)[1]
-            full = np.zeros((kh * kw, npad, cs * 32), np.float32)
-            full[:, :cout, :cin] = np.asarray(w, np.float32).reshape(cout, cin, kh * kw).transpose(2, 0, 1)
-            w3 = split3_bf16(full).reshape(3, kh * kw, npad, cs, 32).transpose(1, 3, 0, 2, 4)
+            if x.C < 32:      # flat: k = tap * Cin_phys + channel, slabs of 32 consecutive k, zero rows behind the last tap
+                nsl = (kh * kw * x.C + 31) // 32
+                flat = np.zeros((npad, nsl * 32), np.float32)
+                wt = np.zeros((cout, kh * kw, x.C), np.float32)
+                wt[:, :, :cin] = np.asarray(w, np.float32).reshape(cout, cin, kh * kw).transpose(0, 2, 1)
+                flat[:cout, :kh * kw * x.C] = wt.reshape(cout, -1)
+                w3 = split3_bf16(flat).reshape(3, npad, nsl, 32).transpose(2, 0, 1, 3)       # [slab][plane][n][32]
+            else:
+                full = np.zeros((kh * kw, npad, cs * 32), np.float32)
+                full[:, :cout, :cin] = np.asarray(w, np.float32).reshape(cout, cin, kh * kw).transpose(2, 0, 1)
+                w3 = split3_bf16(full).reshape(3, kh * kw, npad, cs, 32).transpose(1, 3, 0, 2, 4)
             op.w_off = self.add_weight(np.ascontiguousarray(w3).reshape(-1).view(np.float32))
             op.flags |= L.OPF_SPLIT3
         else:

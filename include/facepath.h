@@ -157,7 +157,8 @@ typedef struct fp_op {
  *                vector rate).  Accepted (exactly fp_plan_validate's list): FP_OP_DWBLOCK stride 1 with (Cin, H = W) in
  *                {(128, 14), (128, 7), (64, 28)} and stride 2 with (Cin, Cmid, Cout, H) in {(64, 128, 64, 56),
  *                (64, 256, 128, 28), (128, 512, 128, 14)} (layouts under "DWBLOCK"); FP_OP_CONV 1x1 stride 1 or 3x3 pad 1
- *                stride 1 / 2, dense views, Cin and Cout multiples of 4 and >= 32 (weights [tap * ceil(Cin / 32) + slab][3
+ *                stride 1 / 2, dense views, Cin and Cout multiples of 4 and >= 32, or 3x3 with Cin 8 / 16 / 24 (K flattened: k = tap * Cin
+ *                + channel in slabs of 32) (weights [tap * ceil(Cin / 32) + slab][3
  *                planes][Npad][32] bf16, zero rows / columns in the padding); FP_OP_DWPW 3x3 pad 1 with Cin a multiple of
  *                32 (<= 256) and Cout 64 or 128; FP_OP_BLAZECHAIN (always).  The semantics of the ops do not change.
  */

@@ -859,6 +859,9 @@ def test_pwx6_pointwise_conv_vs_torch(dev, k, n, act, res_mode, shape, in_slice)
     (184, 184, 1, 1, "silu", "none", (2, 20, 20)),     # pointwise with a width pwx6_kernel does not take
     (720, 360, 1, 1, "silu", "none", (1, 20, 20)),     # 23 K slabs (the last one half full)
     (360, 48, 1, 1, "none", "none", (2, 10, 10)),      # Detect head of yolov5s
+    (16, 32, 3, 2, "silu", "none", (2, 48, 40)),       # yolov5n stem_2b: K flattened over (tap, channel): 144 -> five slabs, two column tiles
+    (24, 48, 3, 1, "relu", "none", (2, 21, 23)),       # 24 channels: a slab holds one tap and a third of the next
+    (8, 32, 3, 1, "none", "after", (1, 24, 20)),       # 8 channels: four taps per slab, the ninth alone in the third
 ])
 def test_convx6_general_conv_vs_torch(dev, cin, cout, ks, stride, act, res_mode, shape):
     """convx6_kernel (csrc/pwx6.hip: 3x3 pad-1 convs and odd-width pointwise convs on the bf16x6 split MFMA) against torch's
