@@ -96,7 +96,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
     return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
-  if (in_rp && !fp_blazeblock_wp_eligible(op) && !fp_blazeblock_wps_eligible(op) && !fp_blazepair_supported(op))
+  if (in_rp && !fp_blazeblock_wp_eligible(op) && !fp_blazeblock_wps_eligible(op) && !fp_blazepair_supported(op) &&
+      !fp_blazepair_s2_supported(op))
     return FP_ERR_UNSUPPORTED;
   if (out_rp && !(op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_STEM_U8 || op.kind == FP_OP_COPY ||
                   (op.kind == FP_OP_CONV && fp_stem_eligible(op))))
@@ -173,9 +174,11 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   }
   if (op.kind == FP_OP_BLAZEPAIR) {
     // both blocks' parameters back to back (facepath.h BLAZEPAIR)
-    if (!fp_blazepair_supported(op)) return FP_ERR_UNSUPPORTED;
+    // stride 2: the second block is the stride-2 block behind a stride-1 block (24 -> 24 or 24 -> 48; blazepairs2.hip)
+    if (op.stride == 2 ? !fp_blazepair_s2_supported(op) : !fp_blazepair_supported(op)) return FP_ERR_UNSUPPORTED;
+    const int64_t pw2 = op.stride == 2 && op.Cout == 48 ? 2 * 768 : 768, c2 = op.stride == 2 ? op.Cout : 24;
     if (!span_ok(op.w_off, 2 * 9 * 24, weight_floats) || !span_ok(op.scale_off, 2 * 24, weight_floats) ||
-        !span_ok(op.slope_off, 2 * 768, weight_floats) || !span_ok(op.bias_off, 2 * 24, weight_floats))
+        !span_ok(op.slope_off, 768 + pw2, weight_floats) || !span_ok(op.bias_off, 24 + c2, weight_floats))
       return FP_ERR_BOUNDS;
   }
   if (op.kind == FP_OP_BLAZECHAIN) {
@@ -314,6 +317,10 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "blazechain96_kernel");
       return buf;
     case FP_OP_BLAZEPAIR:
+      if (op->stride == 2) {
+        snprintf(buf, sizeof(buf), "blazepair_s2_kernel<%d, %d>", op->W, op->Cout);
+        return buf;
+      }
       snprintf(buf, sizeof(buf), "blazepair_kernel<%d>", op->W);
       return buf;
     case FP_OP_DWBLOCK:
@@ -361,7 +368,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
       return (op.flags & FP_OPF_SPLIT3) ? fp_launch_dwpwx6(op, weights, arena, s) : fp_launch_dwpw(op, weights, arena, s);
     case FP_OP_DWBLOCK:
       return (op.flags & FP_OPF_SPLIT3) ? fp_launch_dwblock_x6(op, weights, arena, s) : fp_launch_dwblock(op, weights, arena, s);
-    case FP_OP_BLAZEPAIR: return fp_launch_blazepair(op, weights, arena, s);
+    case FP_OP_BLAZEPAIR: return op.stride == 2 ? fp_launch_blazepair_s2(op, weights, arena, s) : fp_launch_blazepair(op, weights, arena, s);
     case FP_OP_BLAZECHAIN: return fp_launch_blazechain(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);

@@ -95,6 +95,9 @@ bool fp_dwpw_wave_private(const fp_op& op); // true: dwpw_wp_kernel (projection 
 bool fp_blazepair_supported(const fp_op& op);   // two stride-1 24 -> 24 BlazeBlocks in one kernel (blazepair.hip)
 int fp_blazepair_band_rows(const fp_op& op);
 int fp_launch_blazepair(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_blazepair_s2_supported(const fp_op& op);   // a stride-1 24 -> 24 block + the stride-2 block behind it (blazepairs2.hip)
+int fp_blazepair_s2_band_rows(const fp_op& op);
+int fp_launch_blazepair_s2(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_blazechain_supported(const fp_op& op);  // a run of stride-1 96 -> 96 BlazeBlocks on a 16 x 16 map in one kernel (blazechain.hip)
 int64_t fp_blazechain_w_floats(const fp_op& op);
 int fp_launch_blazechain(const fp_op& op, const float* weights, float* arena, hipStream_t s);

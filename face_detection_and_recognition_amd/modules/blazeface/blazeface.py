@@ -48,6 +48,23 @@ class BlazeBlock(_NoCompute):
         return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and BlazeBlock.PAIR and ok(self) and ok(other) and
                 pb.blazepair_supported(x))
 
+    PAIR_S2 = os.environ.get("FP_BLAZE_PAIR_S2", "1") == "1"   # class-wide switch: the single stride-1 24 -> 24 block that ends a stage and
+                                                                # the stride-2 block behind it as ONE op (csrc/blazepairs2.hip)
+
+    def pairs_with_s2(self, other, pb, x):
+        """True if self (stride 1, 24 -> 24) followed by the stride-2 block `other`, fed the row-padded view x, runs as one
+        FP_OP_BLAZEPAIR with stride = 2."""
+        return (BlazeBlock.FUSE and BlazeBlock.ROWPAD and BlazeBlock.PAIR_S2 and isinstance(other, BlazeBlock) and
+                self.kernel_size == 3 and self.stride == 1 and self.in_channels == 24 and self.out_channels == 24 and
+                other.kernel_size == 3 and other.stride == 2 and other.in_channels == 24 and
+                pb.blazepair_s2_supported(x, other.out_channels))
+
+    def emit_pair_s2(self, other, pb, x, out_rowpad=False):
+        y = (pb.new_buf_rowpad if out_rowpad else pb.new_buf)(x.H // 2, x.W // 2, other.out_channels)
+        pb.blazepair_s2(x, [(npy(b.convs[0].weight), npy(b.convs[0].bias), npy(b.convs[1].weight), npy(b.convs[1].bias))
+                            for b in (self, other)], y.view())
+        return y
+
     def emit_pair(self, other, pb, x, out_rowpad=False):
         y = (pb.new_buf_rowpad if out_rowpad else pb.new_buf)(x.H, x.W, 24)
         pb.blazepair(x, [(npy(b.convs[0].weight), npy(b.convs[0].bias), npy(b.convs[1].weight), npy(b.convs[1].bias))
@@ -281,6 +298,9 @@ class BlazeFace(nn.Module):
             elif (isinstance(blk, BlazeBlock) and i + 1 < len(blocks) and isinstance(blocks[i + 1], BlazeBlock) and
                     blk.pairs_with(blocks[i + 1], pb, x.view())):
                 y = blk.emit_pair(blocks[i + 1], pb, x.view(), out_rowpad=rowpad_for(i + 2, x.H, x.W))
+                i += 1
+            elif isinstance(blk, BlazeBlock) and i + 1 < len(blocks) and blk.pairs_with_s2(blocks[i + 1], pb, x.view()):
+                y = blk.emit_pair_s2(blocks[i + 1], pb, x.view(), out_rowpad=rowpad_for(i + 2, x.H // 2, x.W // 2))
                 i += 1
             elif isinstance(blk, BlazeBlock):
                 oh, ow = (x.H // 2, x.W // 2) if blk.stride == 2 else (x.H, x.W)

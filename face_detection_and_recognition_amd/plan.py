@@ -483,6 +483,39 @@ class PlanBuilder:
         return out
 
     @staticmethod
+    def blazepair_s2_supported(x, cout2):
+        """Mirror of fp_blazepair_s2_supported (csrc/blazepairs2.hip): a row-padded 24-channel map, 128 or 64 pixels wide, in
+        front of a stride-1 24 -> 24 block followed by a stride-2 24 -> 24 / 48 block."""
+        return (x.buf.rowpad and x.coff == 0 and x.C == 24 and x.buf.ld == 24 and x.W in (128, 64) and x.H % 2 == 0 and
+                x.H >= 16 and cout2 in (24, 48))
+
+    def blazepair_s2(self, x, blocks, out):
+        """A stride-1 24 -> 24 BlazeBlock and the STRIDE-2 BlazeBlock behind it (blazeface.py:12-47) as ONE op (FP_OP_BLAZEPAIR
+        with stride = 2): blocks = ((dw_w, dw_b, pw_w, pw_b) of the stride-1 block, the same of the stride-2 block); the
+        full-size tensor between them never reaches HBM, `out` is the half-size map (dense or row-padded, ld = its channels)."""
+        cout2 = blocks[1][2].shape[0]
+        assert self.blazepair_s2_supported(x, cout2) and len(blocks) == 2
+        assert out.C == cout2 and out.coff == 0 and out.buf.ld == cout2 and (out.H, out.W) == (x.H // 2, x.W // 2)
+        op = self._base(L.OP_BLAZEPAIR, x, out, out.H, out.W)
+        op.Cout = cout2
+        op.KH = op.KW = 3
+        op.stride = 2
+        op.pad_t = op.pad_l = 0
+        op.act, op.res_mode, op.res_C = L.ACT_RELU, L.RES_POOL2_BEFORE_ACT, 24
+        op.res_ld, op.res_ns, op.res_off, op.res_H, op.res_W = op.in_ld, op.in_ns, op.in_off, x.H, x.W
+        (wd1, bd1, wp1, bp1), (wd2, bd2, wp2, bp2) = blocks
+        assert wd1.shape == (24, 1, 3, 3) and wp1.shape[:2] == (24, 24) and wd2.shape == (24, 1, 3, 3) and wp2.shape[:2] == (cout2, 24)
+        op.w_off = self.add_weight(np.concatenate([pack_dw_weight(wd1, 24), pack_dw_weight(wd2, 24)]))
+        op.scale_off = self.add_weight(np.concatenate([pad_vec(bd1, 24), pad_vec(bd2, 24)]))
+        op.slope_off = self.add_weight(np.concatenate([pack_conv_weight(wp1, 24, 24), pack_conv_weight(wp2, 24, cout2)]))
+        op.bias_off = self.add_weight(np.concatenate([pad_vec(bp1, 24), pad_vec(bp2, cout2)]))
+        self.ops.append(op)
+        pix, opix = x.H * x.W, out.H * out.W
+        # SURVEY 8(d): the stride-1 block's four tensor passes + the stride-2 block's (input, dw output, 1x1 input, output)
+        self.alg_bytes.append(4 * self.N * (pix * 24 * 4 + pix * 24 + opix * 24 + opix * 24 + opix * cout2))
+        return out
+
+    @staticmethod
     def blazechain_supported(x):
         """Mirror of fp_blazechain_supported (csrc/blazechain.hip): a dense 96-channel 16 x 16 map."""
         return (not x.buf.rowpad and x.coff == 0 and x.C == 96 and x.buf.ld == 96 and x.cmul == 1 and x.H == 16 and x.W == 16)
@@ -976,6 +1009,8 @@ class CompiledPlan:
             f = opix * op.KH * op.KW * op.Cin
         elif k in (L.OP_BLAZEBLOCK, L.OP_DWPW):
             f = opix * (9 * op.Cin + op.Cin * op.Cout)
+        elif k == L.OP_BLAZEPAIR and op.stride == 2:
+            f = op.H * op.W * (9 * op.Cin + op.Cin * op.Cin) + opix * (9 * op.Cin + op.Cin * op.Cout)
         elif k == L.OP_BLAZEPAIR:
             f = 2 * opix * (9 * op.Cin + op.Cin * op.Cout)
         elif k == L.OP_BLAZECHAIN:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 7
+#define FP_ABI_VERSION 8
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -231,13 +231,18 @@ typedef struct fp_op {
  *            block's shortcut is its own input).  The two blocks' parameters back to back, each as for BLAZEBLOCK:
  *            w_off -> [2][9][24] taps, scale_off -> [2][24] depthwise bias, slope_off -> [2] packed 1x1 (K = 24,
  *            Npad = 32: 768 floats each), bias_off -> [2][24] 1x1 bias.
+ *            With stride = 2 (ABI 8; csrc/blazepairs2.hip) the SECOND block is the stride-2 block that ends a stage
+ *            (blazeface.py:34-47: F.pad(0, 2, 0, 2), depthwise stride 2, shortcut = 2 x 2 max pool padded on channels): in = x
+ *            as above, out = y2 on the H/2 x W/2 map (dense or FP_OPF_OUT_ROWPAD, out_ld = Cout), Cout = 24 or 48, pad_t =
+ *            pad_l = 0, res_mode = FP_RES_POOL2_BEFORE_ACT; parameters as above with the second block's 1x1 packed for its
+ *            own width (K = 24, Npad = 32 or 64) and bias_off -> [24] then [Cout].
  *   BLAZECHAIN : in = x, out = y (both dense, 96 channels, H = W = 16; in and out may be the same view), Cmid = number of
  *            blocks (1..16); act = FP_ACT_RELU, res_mode = FP_RES_ADD_BEFORE_ACT (each block's shortcut is its own input);
  *            flags = FP_OPF_SPLIT3: the 1x1 convs run as bf16x6 split MFMAs.  w_off -> Cmid blocks back to back, each
  *            [1280 floats: [9][96] depthwise taps (ky*3 + kx), [96] depthwise bias, [96] 1x1 bias, 224 pad] followed by
  *            three slabs (k = 32 s .. 32 s + 31) of [3 planes][96 output channels][32 k] bf16 (13 824 floats).
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -190,7 +190,7 @@ def test_blazeface_row_padded_chain_matches_dense(dev, back, n):
             net = net.to(dev)
             plan = net.plan_for(n)
             names = [plan.kernel_name(i) for i in range(plan.n_ops)]
-            assert any(nm.startswith("blazeblock_wp_kernel") for nm in names) == flag
+            assert any(nm.startswith(("blazeblock_wp_kernel", "blazepair")) for nm in names) == flag     # the row-padded kernels
             r, c = net.raw_from_u8_nhwc(x)
             torch.cuda.synchronize()
             outs[flag] = (r.cpu().numpy().copy(), c.cpu().numpy().copy())
@@ -305,6 +305,66 @@ def test_blazepair_two_blocks_in_one_kernel_vs_oracle(dev, hw, n, out_rp):
         t = blazeface_ref._blaze_block(sd, "", t, 1)
     ref = t.numpy()
     assert outs[True].shape == ref.shape and np.isfinite(outs[True]).all()
+    assert rel_err(outs[True], ref) < 1e-5
+    np.testing.assert_allclose(outs[True], ref, rtol=1e-5, atol=2e-5)
+    assert rel_err(outs[True], outs[False]) < 2e-6
+
+
+@pytest.mark.parametrize("hw,cout2,n,out_rp", [
+    ((128, 128), 24, 3, True),      # BlazeFace-back's first stage end: four strips, two of them make the 64-pixel output rows
+    ((128, 128), 24, 18, False),    # dense output, several bands per image and images per launch
+    ((64, 64), 48, 5, True),        # second stage end: 24 -> 48 (two 32-column halves, channels >= 24 without shortcut), odd band count
+    ((64, 64), 48, 16, False),
+    ((64, 128), 48, 2, True),       # non-square map
+    ((32, 64), 24, 3, False),
+])
+def test_blazepair_s2_stride1_plus_stride2_block_vs_oracle(dev, hw, cout2, n, out_rp):
+    """FP_OP_BLAZEPAIR with stride = 2 (csrc/blazepairs2.hip): a stride-1 24 -> 24 BlazeBlock and the stride-2 block behind it
+    (24 -> 24 / 24 -> 48: F.pad(0, 2, 0, 2), depthwise stride 2, shortcut = channel-padded 2 x 2 max pool) in one kernel, the
+    full-size tensor between them in an LDS ring -- against blazeface_ref._blaze_block applied twice (torch fp32 on the CPU;
+    blazeface.py:12-47) and against the two separate launches (same arithmetic per block: 2e-6 of scale).  The last output
+    row / column read the zero row / pixels of the pad."""
+    H, W = hw
+    rng = np.random.default_rng(900 + H + n + cout2)
+    blks = [BlazeBlock(24, 24), BlazeBlock(24, cout2, stride=2)]
+    sds = []
+    for k, b in enumerate(blks):
+        sd = synth_state_dict(b.state_dict(), 1700 + k)
+        b.load_state_dict(sd)
+        sds.append(sd)
+    x = rng.normal(0, 1, (n, 24, H, W)).astype(np.float32)
+    x[:, :, -1, :] += 1.5         # bottom row / right column distinct: they meet the pad of the stride-2 window
+    x[:, :, :, -1] -= 1.0
+    outs = {}
+    for fused in (True, False):
+        pb = PlanBuilder(n)
+        inp = pb.new_buf_rowpad(H, W, 24)
+        if fused:
+            assert blks[0].pairs_with_s2(blks[1], pb, inp.view())
+            y = blks[0].emit_pair_s2(blks[1], pb, inp.view(), out_rowpad=out_rp)
+        else:
+            mid = blks[0].emit(pb, inp.view(), out_rowpad=False)
+            y = blks[1].emit(pb, mid.view(), out_rowpad=out_rp and blks[1].fused(pb, mid.view()))
+        plan = CompiledPlan(pb, dev)
+        names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+        if fused:
+            assert names == ["blazepair_s2_kernel<%d, %d>" % (W, cout2)], names
+        plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+        yt = plan.buf_tensor(y, n)
+        yt.fill_(float("nan"))
+        for _ in range(2):
+            plan.run()
+        torch.cuda.synchronize()
+        outs[fused] = yt.permute(0, 3, 1, 2).cpu().numpy()
+        if fused and out_rp:        # the pads of a row-padded output stay zero (the next block's window reads them)
+            OW = W // 2
+            full = plan.arena[y.off - (OW + 2) * cout2: y.off - (OW + 2) * cout2 + n * y.ns].clone()
+            yt.zero_()
+            assert float(plan.arena[y.off - (OW + 2) * cout2: y.off - (OW + 2) * cout2 + n * y.ns].abs().max()) == 0.0
+            assert float(full.abs().sum()) > 0
+    t = blazeface_ref._blaze_block(sds[0], "", torch.from_numpy(x), 1)
+    ref = blazeface_ref._blaze_block(sds[1], "", t, 2).numpy()
+    assert outs[True].shape == ref.shape == (n, cout2, H // 2, W // 2) and np.isfinite(outs[True]).all()
     assert rel_err(outs[True], ref) < 1e-5
     np.testing.assert_allclose(outs[True], ref, rtol=1e-5, atol=2e-5)
     assert rel_err(outs[True], outs[False]) < 2e-6

@@ -57,9 +57,44 @@ def test_plans_validate_and_reject_bad_offsets(lib):
     assert lib.fp_plan_validate(None, 0, 0, 0) == -1
 
 
+def test_pair_s2_in_the_blazeface_plan(lib):
+    """FP_OP_BLAZEPAIR with stride = 2 (csrc/blazepairs2.hip): the single stride-1 block that ends each 24-channel stage and the
+    stride-2 block behind it are one op; its output feeds the next stage row-padded; the validator checks both blocks'
+    parameter spans and rejects shapes the kernel does not exist for."""
+    pb = BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0]
+    ops, weights, arena = pb.finish()
+    names = [lib.fp_op_kernel_name(ctypes.byref(op)).decode() for op in ops]
+    both = L.OPF_IN_ROWPAD | L.OPF_OUT_ROWPAD
+    assert names[1:5] == ["blazepair_kernel<128>"] * 3 + ["blazepair_s2_kernel<128, 24>"]
+    assert names[5:9] == ["blazepair_kernel<64>"] * 3 + ["blazepair_s2_kernel<64, 48>"]
+    assert [ops[i].flags for i in (4, 8)] == [both, both] and names[9] == "blazeblock_wps_kernel<48>"
+    assert (ops[4].OH, ops[4].OW, ops[4].Cout, ops[4].stride) == (64, 64, 24, 2) and (ops[8].OH, ops[8].Cout) == (32, 48)
+    arr = (L.FpOp * len(ops))(*ops)
+    assert lib.fp_plan_validate(arr, len(ops), weights.size, arena) == 0
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[8].bias_off = weights.size - 24 - 40        # the stride-2 block's 48 biases would end behind the blob
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[4].Cout = 32                                # only 24 -> 24 and 24 -> 48
+    bad[4].out_ld = 32
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
+    bad = (L.FpOp * len(ops))(*ops)
+    bad[4].flags &= ~L.OPF_IN_ROWPAD                # the ring is fed from a row-padded tensor
+    assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
+
+
 def test_row_padded_views_in_the_blazeface_plan(lib):
     """include/facepath.h FP_OPF_*: the back model keeps the tensors between its 24 -> 24 stride-1 blocks row-padded;
-    the validator rejects the flags on ops that cannot honour them and views whose pads would leave the arena."""
+    the validator rejects the flags on ops that cannot honour them and views whose pads would leave the arena.  (With the
+    stage-end fusion off, BlazeBlock.PAIR_S2 = False: every stage ends with a single block and a stride-2 block.)"""
+    BlazeBlock.PAIR_S2 = False
+    try:
+        _row_padded_views_in_the_blazeface_plan(lib)
+    finally:
+        BlazeBlock.PAIR_S2 = True
+
+
+def _row_padded_views_in_the_blazeface_plan(lib):
     pb = BlazeFace(True)._emit(4, frame_hw=(576, 1024))[0]
     ops, weights, arena = pb.finish()
     flags = [op.flags for op in ops]
