@@ -486,8 +486,8 @@ class PlanBuilder:
     def blazepair_s2_supported(x, cout2):
         """Mirror of fp_blazepair_s2_supported (csrc/blazepairs2.hip): a row-padded 24-channel map, 128 or 64 pixels wide, in
         front of a stride-1 24 -> 24 block followed by a stride-2 24 -> 24 / 48 block."""
-        return (x.buf.rowpad and x.coff == 0 and x.C == 24 and x.buf.ld == 24 and x.W in (128, 64) and x.H % 2 == 0 and
-                x.H >= 16 and cout2 in (24, 48))
+        return (x.buf.rowpad and x.coff == 0 and x.C == 24 and x.buf.ld == 24 and x.W in (128, 64) and x.H % 8 == 0 and
+                x.H >= 16 and cout2 in (24, 48))      # H / 2 output rows in bands of a multiple of 4, at least two bands
 
     def blazepair_s2(self, x, blocks, out):
         """A stride-1 24 -> 24 BlazeBlock and the STRIDE-2 BlazeBlock behind it (blazeface.py:12-47) as ONE op (FP_OP_BLAZEPAIR

@@ -317,6 +317,8 @@ def test_blazepair_two_blocks_in_one_kernel_vs_oracle(dev, hw, n, out_rp):
     ((64, 64), 48, 16, False),
     ((64, 128), 48, 2, True),       # non-square map
     ((32, 64), 24, 3, False),
+    ((16, 64), 24, 1, True),        # the smallest map: two bands of four output rows, one image
+    ((40, 128), 48, 1, False),      # 20 output rows = five bands of four
 ])
 def test_blazepair_s2_stride1_plus_stride2_block_vs_oracle(dev, hw, cout2, n, out_rp):
     """FP_OP_BLAZEPAIR with stride = 2 (csrc/blazepairs2.hip): a stride-1 24 -> 24 BlazeBlock and the stride-2 block behind it
