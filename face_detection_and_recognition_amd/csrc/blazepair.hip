@@ -293,7 +293,7 @@ int launch_pair(const BlazePairArgs& a, hipStream_t s) {
 int fp_blazepair_band_rows(const fp_op& op) {
   const int nsub = 4 / (op.W / 32);
   int best = 0;
-  for (int r = 8; r <= FP_PAIR_MAX_ROWS && r <= op.H; r += 4) {
+  for (int r = 8; r <= FP_PAIR_MAX_ROWS && 2 * r <= op.H; r += 4) {      // at least two bands per image (the kernel's band index math)
     if (op.H % r) continue;
     if (best == 0 || (long)op.N * (op.H / r) / nsub >= 512) best = r;
   }

@@ -293,7 +293,7 @@ int launch_pair_s2(const BlazePairS2Args& a, hipStream_t s) {
 int fp_blazepair_s2_band_rows(const fp_op& op) {
   const int nsub = 4 / (op.W / 32);
   int best = 0;
-  for (int r = 4; r <= 32 && r <= op.OH; r += 4) {
+  for (int r = 4; r <= 32 && 2 * r <= op.OH; r += 4) {    // at least two bands per image
     if (op.OH % r) continue;
     if (best == 0 || (long)op.N * (op.OH / r) / nsub >= 512) best = r;
   }
@@ -330,8 +330,7 @@ int fp_launch_blazepair_s2(const fp_op& op, const float* weights, float* arena, 
   a.out_rp = (op.OW + ((op.flags & FP_OPF_OUT_ROWPAD) ? 1 : 0)) * op.Cout;
   a.in_ns = op.in_ns;
   a.out_ns = op.out_ns;
-  a.bands_div = fp_make_divisor((unsigned)(a.bands >= 2 ? a.bands : 2));
-  if (a.bands < 2) return FP_ERR_UNSUPPORTED;
+  a.bands_div = fp_make_divisor((unsigned)a.bands);      // >= 2 by fp_blazepair_s2_band_rows
   if (op.Cout == 24) return op.W == 128 ? launch_pair_s2<128, 24>(a, s) : launch_pair_s2<64, 24>(a, s);
   return op.W == 128 ? launch_pair_s2<128, 48>(a, s) : launch_pair_s2<64, 48>(a, s);
 }

@@ -57,6 +57,16 @@ def test_plans_validate_and_reject_bad_offsets(lib):
     assert lib.fp_plan_validate(None, 0, 0, 0) == -1
 
 
+def test_blazeface_plans_validate_at_any_batch(lib):
+    """The band rules of the pair kernels depend on the batch (fp_blazepair_band_rows: fewer, longer bands when there are many
+    images): every batch size must still give a plan the validator accepts (a 64-row band on the 64 x 64 map -- one band per
+    image -- once made batches >= 1024 fail)."""
+    for n in (1, 2, 5, 64, 256, 1000, 1024, 4096):
+        for back in (True, False):
+            pb = BlazeFace(back)._emit(n, frame_hw=(576, 1024) if back else None)[0]
+            assert validate_on_host(pb) == 0, (n, back)
+
+
 def test_pair_s2_in_the_blazeface_plan(lib):
     """FP_OP_BLAZEPAIR with stride = 2 (csrc/blazepairs2.hip): the single stride-1 block that ends each 24-channel stage and the
     stride-2 block behind it are one op; its output feeds the next stage row-padded; the validator checks both blocks'
