@@ -1,0 +1,30 @@
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.getcwd())
+from face_detection_and_recognition_amd import workload as W
+dev = torch.device("cuda:0")
+det = W.build_detector(dev, W.make_frames(8, dev, seed=8), cand_per_frame=48)
+frames = W.make_frames(1030, dev, seed=77)
+ref = None
+for n in (8, 1, 7, 300, 1024, 1030):
+    out = det.raw_batch(frames[:n])
+    torch.cuda.synchronize()
+    dets, counts = out[0], out[1]
+    k = min(n, 8)
+    cur = (dets[:k].cpu().numpy().copy(), counts[:k].cpu().numpy().copy())
+    if ref is None:
+        ref = cur
+    else:
+        kk = min(k, 8)
+        ok = np.array_equal(cur[1][:kk], ref[1][:kk]) and all(np.allclose(cur[0][i, :cur[1][i]], ref[0][i, :ref[1][i]], atol=1e-4) for i in range(kk))
+        print("blazeface batch", n, "first", kk, "frames equal to the batch-8 run:", ok, "faces", int(counts.sum()))
+emb = W.build_embedder(dev)
+x = torch.randn((3000, 112, 112, 4), device=dev); x[..., 3] = 0
+base = None
+for n in (8, 1, 3, 100, 1025, 3000):
+    p = emb.plan_for(n)
+    p.input.copy_(x[:n])
+    p.run()
+    torch.cuda.synchronize()
+    e = p.out[:min(n, 3)].cpu().numpy().copy() if hasattr(p, "out") else None
+    if base is None: base = e
+    else: print("mobilefacenet batch", n, "max |diff| vs batch 8:", float(np.abs(e[:min(n,3)] - base[:min(n,3)]).max()))
