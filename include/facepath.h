@@ -71,7 +71,8 @@ enum fp_op_kind {
   FP_OP_STEM_U8 = 11,   /* first conv of a network (KxK in {3,5}, stride 2, Cout <= 64, dense NHWC output; BlazeFace's stem,
                            blazeface.py:118-120,195) reading the u8 frames the same way; needs fp_plan_run_ext */
   FP_OP_BLAZEPAIR = 13, /* TWO consecutive stride-1 24 -> 24 BlazeBlocks (blazeface.py:12-47,122-152) in one kernel: the tensor
-                           between them stays in an LDS ring.  Row-padded input, 128- or 64-pixel-wide map; see "BLAZEPAIR" */
+                           between them stays in an LDS ring.  Row-padded input, 128- or 64-pixel-wide map; with stride = 2 the second block is
+                           the stride-2 block that ends the stage (24 -> 24 / 48, half-size output); see "BLAZEPAIR" */
   FP_OP_BLAZECHAIN = 14, /* a RUN of fp_op.Cmid consecutive stride-1 96 -> 96 BlazeBlocks on the 16 x 16 map (blazeface.py:12-47,
                            146-152) in one kernel: one image per workgroup stays in LDS for the whole run.  See "BLAZECHAIN" */
   FP_OP_DWBLOCK = 12    /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
