@@ -18,6 +18,8 @@
 //   * operands swapped (D^T = W^T A^T): a lane ends with 4 consecutive output channels of ONE pixel: bias + shortcut (from
 //     the LDS image) + ReLU on 16-byte pieces, written back in place (the last block: to global memory).
 // Four workgroup barriers per block: one per weight slab, one between the last depthwise read of the image and its update.
+#include <stdlib.h>
+
 #include "split.h"
 
 namespace {
@@ -39,7 +41,7 @@ struct ChainArgs {
   float* out;
   const float* w;
   long in_ns, out_ns;
-  int nblk;
+  int nblk, N;
 };
 
 // column x - 1 / x + 1 of the same image row and channel (0 outside the row)
@@ -58,8 +60,6 @@ __global__ __launch_bounds__(512, 1) void blazechain96_kernel(ChainArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const float* in = p.in + fp_uniform((long)blockIdx.x * p.in_ns);
-  float* out = p.out + fp_uniform((long)blockIdx.x * p.out_ns);
   const int nblk = p.nblk, nslab = 3 * nblk;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 
@@ -78,6 +78,12 @@ __global__ __launch_bounds__(512, 1) void blazechain96_kernel(ChainArgs p) {
                                        (lds_ptr)((unsigned char*)(par + (b & 1) * PARP) + wave * 1024), 16, 0, 0);
   };
 
+  // persistent over images: the launcher may start fewer workgroups than images (FP_CHAIN_GRID / co-scheduled plans: a
+  // workgroup owns its CU's LDS, so a capped grid leaves the other CUs to whatever runs beside this kernel)
+  for (int img_i = blockIdx.x; img_i < p.N; img_i += gridDim.x) {
+  const float* in = p.in + fp_uniform((long)img_i * p.in_ns);
+  float* out = p.out + fp_uniform((long)img_i * p.out_ns);
+  __syncthreads();      // every wave is done with the previous image (its last epilogue read the LDS image)
   stage(0);
   stage_par(0);
   // the image: 256 px x 24 float4, dense in global memory, pixel stride PS in LDS; zero rows above and below
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(512, 1) void blazechain96_kernel(ChainArgs p) {
       }
     }
   }
+  }
 }
 
 }  // namespace
@@ -218,12 +225,18 @@ int fp_launch_blazechain(const fp_op& op, const float* weights, float* arena, hi
   a.in_ns = op.in_ns;
   a.out_ns = op.out_ns;
   a.nblk = op.Cmid;
+  a.N = op.N;
+  int grid = op.N;
+  if (const char* e = getenv("FP_CHAIN_GRID")) {      // lab: cap the number of workgroups (= CUs this kernel occupies)
+    const int cap = atoi(e);
+    if (cap > 0 && cap < grid) grid = cap;
+  }
   const hipError_t ae = hipFuncSetAttribute((const void*)blazechain96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
     return FP_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(blazechain96_kernel, dim3(op.N), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(blazechain96_kernel, dim3(grid), dim3(512), LDS_BYTES, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }

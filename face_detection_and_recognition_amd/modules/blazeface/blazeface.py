@@ -267,7 +267,8 @@ class BlazeFace(nn.Module):
         blocks = seq[2:]
 
         def chain_len(i, h, w):    # blocks[i:i + n] on an h x w map run as one FP_OP_BLAZECHAIN (0: they do not)
-            if not (BlazeBlock.FUSE and BlazeBlock.CHAIN and not self.co_scheduled and PlanBuilder.X6 and (h, w) == (16, 16)):
+            if not (BlazeBlock.FUSE and BlazeBlock.CHAIN and (not self.co_scheduled or os.environ.get("FP_CHAIN_CO") == "1") and
+                    PlanBuilder.X6 and (h, w) == (16, 16)):
                 return 0
             n = 0
             while i + n < len(blocks) and isinstance(blocks[i + n], BlazeBlock) and blocks[i + n].chains():
