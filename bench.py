@@ -4,8 +4,9 @@ batch 256 per GPU (BASELINE.json configs[1]: BlazeFace back-camera 256^2 -> Mobi
 
   python bench.py                         # 1 GPU, 200 timed steps after 10 warm-ups
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps K --warmup W        # N > 1: starts N ranks ITSELF (launch_ranks below), one per GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W         # ... or runs as one rank of an external launcher (WORLD_SIZE set)
 
 One step = one pass of the hot path over one batch of 256 frames already resident in HBM: letterbox+normalise ->
 BlazeFace-back forward -> anchor decode -> weighted NMS -> detections-to-crops -> crop/resize/normalise ->
@@ -31,6 +32,89 @@ import os
 import sys
 import time
 
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` without an external launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1, GPU_MAX_HW_QUEUES=8 -- see below), relay rank 0's single JSON line
+    to this process's stdout and return non-zero if any rank fails or the line does not report n_gpus == N.  The parent
+    imports neither torch nor the HIP library and makes NO GPU call (a process that has touched the GPU must not be
+    replaced or forked from); children are started with subprocess (fork + exec of a fresh interpreter) and stopped, if
+    one of them dies, by their exact PIDs."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("GPU_MAX_HW_QUEUES", "8")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, cores // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "1500"))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        if time.time() > deadline:
+            failed = (-1, 124)
+        time.sleep(0.05)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+    if failed is not None:
+        for p in procs:                       # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 10
+        for p in procs:
+            while p.poll() is None and time.time() < t_kill:
+                time.sleep(0.05)
+            if p.poll() is None:
+                p.kill()
+        procs[0].stdout.close()
+        sys.stderr.write(f"bench.py launcher: rank {failed[0]} failed (exit code {failed[1]}); all ranks stopped\n"
+                         if failed[0] >= 0 else "bench.py launcher: timed out; all ranks stopped\n")
+        return failed[1] if 0 < failed[1] < 256 else 1
+    out = procs[0].stdout.read().decode()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    try:
+        rec = json.loads(lines[-1])
+    except Exception:
+        sys.stderr.write(f"bench.py launcher: rank 0 printed no JSON line (stdout: {out[-300:]!r})\n")
+        return 1
+    if len(lines) != 1 or rec.get("n_gpus") != n or (rec.get("launch") or {}).get("world_size") != n:
+        sys.stderr.write(f"bench.py launcher: asked for {n} ranks, the line reports n_gpus = {rec.get('n_gpus')}, "
+                         f"world_size = {(rec.get('launch') or {}).get('world_size')} ({len(lines)} line(s))\n")
+        return 1
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    sys.exit(launch_ranks(_requested_gpus(sys.argv[1:]), sys.argv[1:]))      # before torch / HIP are even imported
+
 # The step runs on up to four streams (detector, embedder, cross-rank exchange, RCCL's own).  HIP maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin: with the default, the embedder's stream lands on the detector's
 # queue once the process group exists, and the two networks serialise (4.69 ms per step against 4.15 in the one-GPU RCCL
@@ -48,6 +132,7 @@ from face_detection_and_recognition_amd import similarity as S  # noqa: E402
 from face_detection_and_recognition_amd import workload as W  # noqa: E402
 from face_detection_and_recognition_amd.pipeline import FacePipeline  # noqa: E402
 
+DTYPE_LABEL = "f32 (bf16x6 split GEMMs)"   # fp32 operands and accumulation; the GEMM products as six bf16 MFMA products (csrc/split.h)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (= the fp32 vector rate); SURVEY 8(d)'s fp32 roofline
 BF16_MFMA_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak
@@ -56,7 +141,7 @@ MFMA_F32_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 B_FRAMES = 256
 N_BATCHES = 4              # distinct frame batches the timed steps rotate through
 N_REF = 10000
-EMB_CAP_ROWS = 1024        # all_gather block rows per rank (>= faces per step per rank; ~512 at 2 faces / frame)
+EMB_CAP_ROWS = 1024        # STARTING all_gather block rows per rank (~512 faces per step at 2 faces / frame); StepExchange grows it
 FRAME_BYTES = 576 * 1024 * 3
 LETTERBOX_OUT_BYTES = 256 * 256 * 3 * 4
 
@@ -156,6 +241,70 @@ def init_dist():
     return world, rank, dev, dist, backend
 
 
+def check_world(args, world):
+    """`--gpus` must be the number of ranks that actually run: a line that says n_gpus = 1 for a `--gpus 8` command (or the
+    reverse) would be a scaling point measured on the wrong job.  Fails on every rank, before any work."""
+    if args.gpus != world and not os.environ.get("BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: run `python bench.py --gpus {args.gpus}` "
+                         f"(it starts the ranks itself) or launch exactly --gpus ranks")
+
+
+def launch_record(args, world, rank, dev, dist, backend, count):
+    """What the result line says about the job's shape: the world size the process group itself reports, the collective
+    library, every rank's device and every rank's share of the processed units (all gathered through the group)."""
+    rec = {"mode": "self-launched (bench.py started the ranks)" if os.environ.get("BENCH_LAUNCHED_BY") == "bench.py"
+           else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "in-process, one rank"),
+           "requested_gpus": args.gpus, "world_size": world, "backend": None, "units_per_rank": [count], "devices": None}
+    if dist is None:
+        return rec
+    mine = {"rank": rank, "units": int(count), "device": str(dev)}
+    if dev is not None and dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        mine["device"] = f"{dev} {props.name}" + (f" {props.uuid}" if hasattr(props, "uuid") else "")
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, mine)
+    rec["world_size"] = dist.get_world_size()
+    rec["units_per_rank"] = [g["units"] for g in got]
+    rec["devices"] = [g["device"] for g in got]
+    if backend == "nccl":
+        rec["backend"] = "nccl = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+    else:
+        rec["backend"] = backend + " (CPU rehearsal)"
+    return rec
+
+
+def run_stub(args):
+    """BENCH_STUB_STEP=1 (tests, no GPU): the launcher, the rendezvous, the reductions and the result line with a stub in
+    place of the step -- every rank 'finds' 100 + rank faces per step in a gloo group on the CPU."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    check_world(args, world)
+    if os.environ.get("BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t0 = time.perf_counter()
+    faces = 0
+    for _ in range(args.steps):
+        time.sleep(0.001)
+        faces += 100 + rank
+    dist.barrier()
+    elapsed, faces_all = reduce_time_and_count(time.perf_counter() - t0, faces, max(world, 2), dist, None, "gloo")
+    launch = launch_record(args, world, rank, torch.device("cpu"), dist, "gloo", faces)
+    if rank == 0:
+        emit_line({"metric": "faces/sec end-to-end (detect->embed->cosine-filter), 576x1024 batch=256", "stub": True,
+                   "value": round(faces_all / elapsed, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                   "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL, "data": "synthetic",
+                   "config": {"workload": "STUB step (launcher test, no GPU work)"}, "launch": launch,
+                   "roofline": None, "cpu_baseline": None})
+    dist.destroy_process_group()
+
+
 def reduce_time_and_count(elapsed, count, world, dist, dev, backend):
     """MAX of the elapsed time and SUM of the processed units over ranks."""
     if world == 1 or dist is None:
@@ -170,6 +319,7 @@ def reduce_time_and_count(elapsed, count, world, dist, dev, backend):
 
 # ---------------------------------------------------------------------------------------------------------------
 def run_pipeline(args):
+    check_world(args, int(os.environ.get("WORLD_SIZE", "1")))
     world, rank, dev, dist, backend = init_dist()
     from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise
     Depth_Wise.X6 = args.mfma == "bf16x6"
@@ -297,6 +447,7 @@ def run_pipeline(args):
         p._timing = None
 
     elapsed, faces_all = reduce_time_and_count(t1 - t0, faces, world if not multi else max(world, 2), dist, dev, backend)
+    launch = launch_record(args, world, rank, dev, dist, backend, faces)
 
     # ---- roofline of the dominant kernel family (rank 0) ----
     roof = None
@@ -417,12 +568,19 @@ def run_pipeline(args):
                "sample": f"first {nfr} frames of batch 0 (time-boxed), one frame per call like the reference: "
                          f"{n_cpu} faces in {dt:.1f} s, torch-CPU fp32 oracle"}
 
+    # ---- the other BASELINE configs, short legs after the timed region (rank 0, N = 1): driver-visible, not the headline ----
+    others = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        from tools.config_bench import other_configs
+        others = other_configs(dev)
+
     if rank == 0:
         line = {
             "metric": "faces/sec end-to-end (detect->embed->cosine-filter), 576x1024 batch=256",
             "value": round(faces_all / elapsed, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL if args.mfma == "bf16x6" else "f32", "data": "synthetic",
+            "launch": launch,
             "config": {"workload": "BlazeFace back-camera 256x256, batch 256 synthetic 576x1024 frames per GPU -> "
                                    "weighted NMS -> Mobile-FaceNet 112x112 -> cosine filter vs 10k x 512 reference",
                        "frames_per_step_per_gpu": B_FRAMES, "frame_batches_rotated": N_BATCHES,
@@ -434,7 +592,7 @@ def run_pipeline(args):
                                        f"{'RCCL' if backend == 'nccl' else backend + ' (CPU rehearsal)'} + cross-rank cosine match, "
                                        f"overlapped with the next step's detector (side stream, consumed one step late)"
                                        if world > 1 else "")},
-            "roofline": roof, "cpu_baseline": cpu, "arithmetic": arith,
+            "roofline": roof, "cpu_baseline": cpu, "arithmetic": arith, "other_configs": others,
         }
         emit_line(line)
     if multi:
@@ -445,6 +603,7 @@ def run_pipeline(args):
 def run_c5(args):
     """BASELINE configs[4]: gallery rows sharded 125 k per rank, 10 k reference rows produced sharded (10 k / N per
     rank), one all_gather of the equal reference blocks, then the fused row-max cosine kernel on every rank's shard."""
+    check_world(args, int(os.environ.get("WORLD_SIZE", "1")))
     world, rank, dev, dist, backend = init_dist()
     M, D = args.gallery_rows, 512
     nr_local = N_REF // world
@@ -481,13 +640,14 @@ def run_c5(args):
     t1 = time.perf_counter()
     nr = nr_local * world
     elapsed, rows_all = reduce_time_and_count(t1 - t0, M * args.steps, world, dist, dev, backend)
+    launch = launch_record(args, world, rank, dev, dist, backend, M * args.steps)
     if rank == 0:
         ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
         tf = 2.0 * M * nr * D / (ms * 1e-3) / 1e12
         line = {"metric": "pair-scores/sec, cosine filter gallery x reference x 512-d (fused row max, matrix never written)",
                 "value": round(rows_all * nr / elapsed, 1), "unit": "pair-scores/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL, "data": "synthetic", "launch": launch,
                 "config": {"workload": f"filter_faces_using_reference cosine mode: {M} gallery rows per GPU x {nr} reference "
                                        f"rows x {D}-d, reference produced sharded ({nr_local} rows per rank)",
                            "parallelism": f"gallery row-sharded over {world} rank(s)" +
@@ -539,6 +699,9 @@ def main():
                     help="matrix arithmetic of the Mobile-FaceNet Depth_Wise blocks: bf16x6 = fp32 operands split exactly into "
                          "three bf16 pieces, six products, fp32 accumulation (csrc/split.h; as accurate as the fp32 fmaf chain); "
                          "fp32 = every GEMM on the fp32 MFMA (rounds 1-3)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of BASELINE configs[2], [3], the batch-1024 embedder and the configs[4] shard that "
+                         "fill `other_configs` (1 GPU only)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short un-timed-region leg that re-measures the step "
                                                                "with --mfma fp32 for the `arithmetic` object")
     ap.add_argument("--overlap", type=int, nargs="?", const=1, default=2,
@@ -554,7 +717,9 @@ def main():
         args.steps = 20 if args.workload == "c5" else 200
     if args.warmup is None:
         args.warmup = 3 if args.workload == "c5" else 10
-    if args.workload == "c5":
+    if os.environ.get("BENCH_STUB_STEP") == "1":
+        run_stub(args)
+    elif args.workload == "c5":
         run_c5(args)
     else:
         run_pipeline(args)

@@ -68,6 +68,7 @@ _I64 = C.c_int64
 SIGNATURES = {
     "fp_abi_version": (_I, []),
     "fp_selftest": (_I, []),
+    "fp_debug_reload_env": (None, []),
     "fp_strerror": (C.c_char_p, [_I]),
     "fp_last_hip_error": (C.c_char_p, []),
     "fp_plan_run": (_I, [C.POINTER(FpOp), _I, _P, _SZ, _P, _SZ, _P]),

@@ -227,10 +227,8 @@ int fp_launch_blazechain(const fp_op& op, const float* weights, float* arena, hi
   a.nblk = op.Cmid;
   a.N = op.N;
   int grid = op.N;
-  if (const char* e = getenv("FP_CHAIN_GRID")) {      // lab: cap the number of workgroups (= CUs this kernel occupies)
-    const int cap = atoi(e);
-    if (cap > 0 && cap < grid) grid = cap;
-  }
+  const int cap = fp_get_knobs().chain_grid;           // lab: cap the number of workgroups (= CUs this kernel occupies)
+  if (cap > 0 && cap < grid) grid = cap;
   const hipError_t ae = hipFuncSetAttribute((const void*)blazechain96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);

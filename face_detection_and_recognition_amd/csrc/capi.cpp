@@ -1,6 +1,7 @@
 // capi.cpp — plan validation + executor and the small ABI utilities of libfacepath.so.
 // Compiled by hipcc as host code; kernels live in the .hip files.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -13,9 +14,27 @@ void fp_set_hip_error(hipError_t e) {
   g_hip_err[sizeof(g_hip_err) - 1] = 0;
 }
 
+static int env_int(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+static fp_knobs read_knobs() {
+  fp_knobs k;
+  k.chain_grid = env_int("FP_CHAIN_GRID");
+  k.resize_per_pixel = getenv("FP_RESIZE_PER_PIXEL") != nullptr;
+  k.x6_quarter14 = env_int("FP_X6_QUARTER14");
+  k.x6_spec14 = env_int("FP_X6_SPEC14");
+  k.pwx6_small_maxk = env_int("FP_PWX6_SMALL_MAXK");
+  return k;
+}
+static fp_knobs g_knobs = read_knobs();
+const fp_knobs& fp_get_knobs() { return g_knobs; }
+
 extern "C" {
 
 int fp_abi_version(void) { return FP_ABI_VERSION; }
+
+void fp_debug_reload_env(void) { g_knobs = read_knobs(); }
 
 const char* fp_last_hip_error(void) { return g_hip_err; }
 

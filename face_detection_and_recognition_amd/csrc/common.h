@@ -25,6 +25,17 @@ __device__ __forceinline__ float fp_silu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Lab / test knobs of the launchers, taken from the environment ONCE when the library is loaded (a launch never calls
+// getenv); fp_debug_reload_env() (facepath.h) re-reads them.  0 = the product path for every knob.
+struct fp_knobs {
+  int chain_grid;        // FP_CHAIN_GRID: cap on blazechain96_kernel's workgroups (lab)
+  int resize_per_pixel;  // FP_RESIZE_PER_PIXEL: fp_resize_normalize takes the per-pixel kernel (the tabled kernel's reference in tests)
+  int x6_quarter14;      // FP_X6_QUARTER14: 14 x 14 Depth_Wise blocks as 7 x 7 tiles (lab)
+  int x6_spec14;         // FP_X6_SPEC14: the wave-specialised 14 x 14 form (lab)
+  int pwx6_small_maxk;   // FP_PWX6_SMALL_MAXK: K at or below which pwx6 takes its small tiles (lab)
+};
+const fp_knobs& fp_get_knobs();
+
 // Per-thread record of the last HIP error text (fp_last_hip_error()).
 void fp_set_hip_error(hipError_t e);
 

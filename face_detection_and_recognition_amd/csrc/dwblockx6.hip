@@ -1336,7 +1336,7 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   a.N = op.N;
   a.has_res = op.res_mode == FP_RES_ADD_AFTER_ACT;
   // lab knob: 14x14 as 7x7 tiles (three workgroups per CU; measured slower than the bands: 146 against 126 us at 528 crops)
-  static const int quarter14 = getenv("FP_X6_QUARTER14") ? atoi(getenv("FP_X6_QUARTER14")) : 0;
+  const int quarter14 = fp_get_knobs().x6_quarter14;
   if (op.stride == 2) {
     if (op.H == 56) return (op.flags & FP_OPF_IN_DW) ? launch_x6d<64, 128, 64, 56, true>(a, s) : launch_x6d<64, 128, 64, 56>(a, s);
     return op.Cin == 64 ? launch_x6d<64, 256, 128, 28>(a, s) : launch_x6d<128, 512, 128, 14>(a, s);
@@ -1344,7 +1344,7 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
   if (op.Cin == 128 && op.H == 7) return launch_x6q<7>(a, s);
   // lab knob: the wave-specialised form (matrix waves / vector waves; measured 141 against 126 us at 528 crops: its D phase
   // runs 4500 cycles beside the matrix waves' MFMAs, tools/lab/x6_lab.hip)
-  static const int spec14 = getenv("FP_X6_SPEC14") ? atoi(getenv("FP_X6_SPEC14")) : 0;
+  const int spec14 = fp_get_knobs().x6_spec14;
   if (op.Cin == 128) return quarter14 ? launch_x6q<14>(a, s) : spec14 ? launch_x6s<128, 14>(a, s) : launch_x6<128, 14>(a, s);
   return launch_x6<64, 28>(a, s);
 }

@@ -160,7 +160,7 @@ extern "C" int fp_resize_normalize(const uint8_t* frames, int n_frames, int fram
                pad_value, swap_rb};
   // tabled form: 16-byte pixels, a frame row of at least 8 bytes, rows / offsets that fit the table fields (letterbox.h)
   if (canvas_c == 4 && frame_w >= 3 && frame_w <= 32767 && frame_h <= 65535 && canvas_w >= 2 && canvas_w <= 4096 &&
-      ((uintptr_t)canvas) % 16 == 0 && !getenv("FP_RESIZE_PER_PIXEL")) {
+      ((uintptr_t)canvas) % 16 == 0 && !fp_get_knobs().resize_per_pixel) {
     ResizeRowsArgs q;
     q.a = a;
     q.rpb = (int)min((long)canvas_h, max(1L, 8192L / canvas_w));      // ~8 k pixels per workgroup

@@ -244,14 +244,7 @@ __global__ __launch_bounds__(256, MT_ == 4 ? 2 : 3) void pwx6_kernel(PwX6Args p)
 // rounds of workgroups the large tiles need (512 slots): below 8, and with a last round less than 70 % full -> small tiles
 // K at or below which the small tiles are taken regardless of the round count (0 = never): with two or four K slabs a tile is
 // one HBM round trip + its MFMAs, and three co-resident workgroups with every slab of A in flight hide more of it than two.
-static int pwx6_small_maxk() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FP_PWX6_SMALL_MAXK");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+static int pwx6_small_maxk() { return fp_get_knobs().pwx6_small_maxk; }
 
 bool pwx6_small_tiles(long M, int nchunk) {
   const double rounds = (double)((M + BM - 1) / BM * nchunk) / 512.0;

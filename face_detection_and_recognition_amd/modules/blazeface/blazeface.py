@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...plan import Buf, CompiledPlan, PlanBuilder, PlanCache, View, cpad
+from ...plan import Buf, CompiledPlan, PlanBuilder, PlanCache, View, cpad, switch_key
 from ..params import ConvParams, _NoCompute, npy
 
 
@@ -349,7 +349,9 @@ class BlazeFace(nn.Module):
     def plan_for(self, N, frame_hw=None):
         if self._device().type != "cuda":
             raise L.FacepathError("BlazeFace runs only on a HIP device (model.to('cuda')); there is no CPU path")
-        return self._plans.get((N, frame_hw, self.co_scheduled), lambda cache: self._build(N, cache, frame_hw))
+        key = (N, frame_hw, self.co_scheduled, os.environ.get("FP_CHAIN_CO") == "1",
+               switch_key(PlanBuilder, BlazeBlock, BlazeFace))
+        return self._plans.get(key, lambda cache: self._build(N, cache, frame_hw))
 
     # ------------------------------------------------------------------ inference
     def forward(self, x):

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...plan import CompiledPlan, PlanBuilder, PlanCache, bn_affine
+from ...plan import CompiledPlan, PlanBuilder, PlanCache, bn_affine, switch_key
 from ..params import BNParams, ConvParams, LinearParams, PReLUParams, _NoCompute, npy
 
 
@@ -296,7 +296,12 @@ class MobileFaceNet(nn.Module):
         shapes = Depth_Wise.BLOCK_SHAPES if Depth_Wise.BLOCK_SHAPES is not None else \
             Depth_Wise.block_policy(N if n_run is None else n_run)
         shapes = tuple(shapes)
-        return self._plans.get((N, shapes, Depth_Wise.FUSE, Depth_Wise.X6, MobileFaceNet.X6_CONV23, MobileFaceNet.X6_CONV2_IN), lambda cache: self._build(N, cache, block_shapes=shapes))
+        if Depth_Wise.FUSE and Depth_Wise.X6:
+            # every stride-1 block takes the split whole-block kernel before `shapes` is consulted (Depth_Wise.emit): the op
+            # list does not depend on it, so ONE capacity = ONE plan and one arena whatever n_run is
+            shapes = tuple(h for h in shapes if (128 if h < 28 else 64, h) not in PlanBuilder.DWBLOCK_X6_SHAPES)
+        key = (N, shapes, switch_key(PlanBuilder, Depth_Wise, MobileFaceNet))
+        return self._plans.get(key, lambda cache: self._build(N, cache, block_shapes=shapes))
 
     def forward(self, x):
         b = x.shape[0]

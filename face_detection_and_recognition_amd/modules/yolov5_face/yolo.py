@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...plan import CompiledPlan, PlanBuilder, PlanCache, View, bn_affine, cpad
+from ...plan import CompiledPlan, PlanBuilder, PlanCache, View, bn_affine, cpad, switch_key
 from ..params import BNParams, ConvParams, _NoCompute, npy
 
 # Architecture specs of the reference's in-tree yamls (y5/models/yolov5n.yaml, yolov5s.yaml, yolov5n-0.5.yaml):
@@ -594,7 +594,8 @@ class Model(nn.Module):
     def plan_for(self, N, H=640, W=640, frame_hw=None):
         if self._device().type != "cuda":
             raise L.FacepathError("YOLOv5-face runs only on a HIP device (model.to('cuda')); there is no CPU path")
-        return self._plans.get((N, H, W, frame_hw), lambda cache: self._build(N, H, W, cache, frame_hw))
+        key = (N, H, W, frame_hw, switch_key(PlanBuilder, Conv, StemBlock, C3, ShuffleV2Block, SPP, Concat, Model))
+        return self._plans.get(key, lambda cache: self._build(N, H, W, cache, frame_hw))
 
     def run_plan(self, plan):
         """Forward + Detect decode on whatever is in plan.input.  Returns z (N, n_rows, 16): zero-copy, a view into

@@ -116,7 +116,11 @@ class FacePipeline:
         falls back to the exact un-capped re-run for that batch."""
         dets, counts, over = self.detect(frames, beside=self.emb_stream is not None)
         items, info, nf = self.crops(frames, dets, counts)
-        host = torch.empty((2,), dtype=torch.int32).pin_memory()
+        # two pinned count buffers, used alternately: at most one batch is pending while the previous one's is read
+        if getattr(self, "_host_counts", None) is None:
+            self._host_counts, self._host_k = [torch.empty((2,), dtype=torch.int32).pin_memory() for _ in range(2)], 0
+        host = self._host_counts[self._host_k & 1]
+        self._host_k += 1
         both = nf if over is None else torch.stack([nf[0], over.sum().to(torch.int32)])
         host[:both.numel()].copy_(both, non_blocking=True)
         if over is None:
@@ -157,6 +161,10 @@ class FacePipeline:
                 emb = self.embed(frames, items, n)
                 res = self.filter(emb)
                 out = dict(n_faces=n, info=info[:n], emb=emb.clone(), items=items[:n])
+                # allocated on the side stream, consumed by the caller on the main stream (after `done`): tell the caching
+                # allocator, or it hands the blocks to the next embed / filter while main-stream reads are still queued
+                for t in (out["emb"],) + (tuple(res) if res is not None else ()):
+                    t.record_stream(main)
                 self._emb_done = torch.cuda.Event()
                 self._emb_done.record(self.emb_stream)
             out["done"] = self._emb_done                   # the caller waits for this event before it reads the results

@@ -835,8 +835,21 @@ class PlanBuilder:
         return self.ops, weights, self.peak
 
 
+def switch_key(*classes):
+    """Every class-wide switch of the given classes (their own UPPER_CASE attributes holding a bool / int / float / str /
+    tuple / None: FUSE, ROWPAD, PAIR, CHAIN, FOLD_UPSAMPLE, PlanBuilder.X6, ...) as one hashable tuple.  It is part of
+    every plan-cache key: a plan records the kernels the switches selected when it was emitted, so flipping one after a
+    plan exists must build another plan, not reuse that one."""
+    key = []
+    for cls in classes:
+        for name, v in sorted(vars(cls).items()):
+            if name.isupper() and isinstance(v, (bool, int, float, str, tuple, type(None))):
+                key.append((cls.__name__, name, v))
+    return tuple(key)
+
+
 class PlanCache:
-    """Per-network cache of compiled plans, keyed by batch shape.
+    """Per-network cache of compiled plans, keyed by batch shape + the emit switches (switch_key).
 
     * LRU-bounded (``max_plans``): a plan owns an activation arena of several GB at batch >= 1024, so a caller whose
       batch size varies (FacePipeline's 64-row buckets) must not pin one arena per size it has ever seen.

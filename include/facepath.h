@@ -50,6 +50,13 @@ const char* fp_last_hip_error(void);
  * Returns FP_OK or FP_ERR_INVALID_ARG (with the failing pair in fp_last_hip_error's buffer).
  */
 int fp_selftest(void);
+/*
+ * Lab / test knobs (FP_CHAIN_GRID, FP_RESIZE_PER_PIXEL, FP_X6_QUARTER14, FP_X6_SPEC14, FP_PWX6_SMALL_MAXK) are read from
+ * the environment ONCE, when the library is loaded; no launch calls getenv.  This re-reads them (tests that switch a
+ * knob at run time call it after changing the environment).  Not for production use: it is the library's only
+ * process-wide mutable state, and it must not be called while another thread is launching.
+ */
+void fp_debug_reload_env(void);
 
 /* ------------------------------------------------------------------------- */
 /* 1. Network plans: one flat array of ops, executed back-to-back on a stream. */

@@ -463,3 +463,29 @@ def test_tf_style_preprocess_matches_oracle_and_reference_test_property(dev):
         assert np.allclose(got[i], ref, atol=1e-4)
     const = np.full((1, 40, 40, 3), 77, np.uint8)                         # std = 0 -> divided by 1/sqrt(N), all zeros
     assert np.abs(preprocess_tf_standardize(torch.from_numpy(const).to(dev), (160, 160)).cpu().numpy()).max() < 1e-4
+
+
+def test_bench_gpus_2_self_launch_on_one_gpu(dev):
+    """`python bench.py --gpus 2`, end to end with the REAL step: the launcher starts two ranks, both run the whole
+    detect -> embed -> filter step and the overlapped cross-rank exchange (StepExchange) on this box's one GPU
+    (BENCH_SAME_DEVICE=1; gloo carries the collectives because two RCCL ranks cannot share a device), and the single line
+    on stdout reports n_gpus = 2 = the process group's own world size, with both ranks' face counts.  (The RCCL form of the
+    same code path is rehearsed with BENCH_FORCE_DIST=1; the 8-GPU run is the driver's.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(BENCH_DIST_BACKEND="gloo", BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["launch"]["world_size"] == 2 and rec["launch"]["requested_gpus"] == 2
+    per_rank = rec["launch"]["units_per_rank"]
+    assert len(per_rank) == 2 and all(4 * 256 <= n <= 4 * 256 * 4 for n in per_rank)         # ~2 faces per frame, 4 steps each
+    assert abs(rec["value"] * rec["ms_per_step"] * 4e-3 - sum(per_rank)) <= 1.0                # whole-job faces / max-rank time
+    assert rec["config"]["frames_per_step_per_gpu"] == 256 and "gloo" in rec["launch"]["backend"]

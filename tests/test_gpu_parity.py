@@ -1283,6 +1283,7 @@ def test_resize_tabled_kernel_is_bit_exact(dev, lib, frame_hw, canvas_hw, n_item
     for per_pixel in (False, True):
         if per_pixel:
             os.environ["FP_RESIZE_PER_PIXEL"] = "1"
+        lib.fp_debug_reload_env()          # the library reads its knobs once at load; this re-reads them
         try:
             canvas = torch.full((n_items, ch, cw, 4), float("nan"), device=dev)
             L.check(lib.fp_resize_normalize(L.ptr(frames), 4, fh, fw, L.ptr(it), n_items, L.ptr(canvas), ch, cw, 4, L.ptr(lut),
@@ -1290,6 +1291,7 @@ def test_resize_tabled_kernel_is_bit_exact(dev, lib, frame_hw, canvas_hw, n_item
             torch.cuda.synchronize()
         finally:
             os.environ.pop("FP_RESIZE_PER_PIXEL", None)
+            lib.fp_debug_reload_env()
         out[per_pixel] = canvas.cpu().numpy()
     assert np.isfinite(out[False]).all()
     np.testing.assert_array_equal(out[False], out[True])

@@ -274,6 +274,65 @@ def test_plan_cache_is_lru_bounded_and_shares_weights():
     assert len(cache) == 0 and cache.device_weights(w, torch.device("cpu")) is not d0
 
 
+def test_plan_cache_keys_follow_the_emit_switches(lib, monkeypatch):
+    """a plan records the kernels the class-wide switches selected when it was emitted, so the cache key of all
+    three networks carries every switch (plan.switch_key): flipping PlanBuilder.X6 (= Depth_Wise.X6, `bench.py --mfma fp32`)
+    or Model.FOLD_UPSAMPLE after a plan exists builds ANOTHER plan -- no op of it carries FP_OPF_SPLIT3 -- and flipping
+    back finds the first one again.  Mobile-FaceNet with the split kernels on: one capacity = one plan whatever n_run is
+    (the op list does not depend on Depth_Wise.block_policy then)."""
+    from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import Model
+    cuda = torch.device("cuda")
+    builds = []
+
+    def stub(net, emit):
+        monkeypatch.setattr(net, "_device", lambda: cuda)
+        monkeypatch.setattr(net, "_build", lambda *a, **kw: builds.append(1) or emit(*a, **kw))
+
+    net = BlazeFace(True)
+    stub(net, lambda N, cache, frame_hw=None: net._emit(N, frame_hw)[0].finish()[0])
+    ops1 = net.plan_for(4, (576, 1024))
+    assert any(op.kind == L.OP_BLAZECHAIN and op.flags & L.OPF_SPLIT3 for op in ops1)
+    Depth_Wise.X6 = False
+    try:
+        ops2 = net.plan_for(4, (576, 1024))
+        assert ops2 is not ops1 and not any(op.flags & L.OPF_SPLIT3 for op in ops2)
+    finally:
+        Depth_Wise.X6 = True
+    assert net.plan_for(4, (576, 1024)) is ops1
+    BlazeBlock.PAIR = False
+    try:
+        assert not any(op.kind == L.OP_BLAZEPAIR and op.stride == 1 for op in net.plan_for(4, (576, 1024)))
+    finally:
+        BlazeBlock.PAIR = True
+
+    m = Model("yolov5n")
+    stub(m, lambda N, H, W, cache, frame_hw=None: m._emit(N, H, W, frame_hw)[0].finish()[0])
+    y1 = m.plan_for(2, 128, 128)
+    assert any(op.flags & L.OPF_IN_UP2 for op in y1) and any(op.flags & L.OPF_SPLIT3 for op in y1)
+    Model.FOLD_UPSAMPLE = False
+    PlanBuilder.X6 = False
+    try:
+        y2 = m.plan_for(2, 128, 128)
+        assert not any(op.flags & (L.OPF_IN_UP2 | L.OPF_SPLIT3) for op in y2)
+    finally:
+        Model.FOLD_UPSAMPLE, PlanBuilder.X6 = True, True
+    assert m.plan_for(2, 128, 128) is y1
+
+    e = MobileFaceNet(512)
+    stub(e, lambda N, cache, block_shapes=None: e._emit(N, block_shapes=block_shapes)[0].finish()[0])
+    n0 = len(builds)
+    p_small, p_large = e.plan_for(768, n_run=200), e.plan_for(768, n_run=528)    # block_policy differs: (), (7,)
+    assert Depth_Wise.block_policy(200) != Depth_Wise.block_policy(528)
+    assert p_small is p_large and len(builds) == n0 + 1
+    Depth_Wise.X6 = False
+    try:
+        f_small, f_large = e.plan_for(768, n_run=200), e.plan_for(768, n_run=528)
+        assert f_small is not f_large and not any(op.flags & L.OPF_SPLIT3 for op in f_small + f_large)
+    finally:
+        Depth_Wise.X6 = True
+
+
 def test_fused_letterbox_plans_validate_on_host(lib):
     """The plans whose first op reads u8 frames (FP_OP_STEM_U8 / FP_OP_YSTEM_U8) pass the C validator; the ops that
     need external buffers are rejected by plain fp_plan_run-style validation of their shapes only when malformed."""

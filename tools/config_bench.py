@@ -28,6 +28,12 @@ def timeit(fn, n=5, warm=2):
     return (time.perf_counter() - t0) / n
 
 
+# SURVEY 8(d) / BASELINE.md section 3: per-GPU rooflines of the op-granular model (img/s, crops/s, TFLOP/s)
+ROOF_YOLO_IMG_S = {"yolov5n": 28.5e3, "yolov5s": 19.2e3}
+ROOF_MFN_CROPS_S = 310e3
+ROOF_FP32_MFMA_TF = 157.3
+
+
 def yolo(name, dev, B=256, cand_per_frame=80):
     """BASELINE configs[2]: letterbox + forward + Detect decode + batched NMS with ~cand_per_frame candidates per image
     (objectness calibrated off the clock, workload.build_yolo_detector)."""
@@ -42,16 +48,17 @@ def yolo(name, dev, B=256, cand_per_frame=80):
     out, cnt, _, over = nms_face_device(z, 0.4, 0.5)
     cand = float(((z[..., 4] > 0.4) & (z[..., 4] * z[..., 15] > 0.4)).sum(1).float().mean())
     alg = sum(plan.algorithmic_bytes(i) for i in range(plan.n_ops))
-    print(json.dumps({"config": f"{name}-face 640x640 batch {B} + batched NMS", "letterbox_ms": round(t_pre * 1e3, 3),
-                      "forward_decode_ms": round(t_fwd * 1e3, 3), "nms_ms": round(t_nms * 1e3, 3),
-                      "img_per_s": round(B / (t_pre + t_fwd + t_nms), 1), "cand_per_img": round(cand, 1),
-                      "dets_per_img": round(float(cnt.float().mean()), 2),
-                      "overflow": int(over.sum()), "algorithmic_GBps_forward": round(alg / t_fwd / 1e9, 1),
-                      "n_ops": plan.n_ops}), flush=True)
-    return det
+    rate = B / (t_pre + t_fwd + t_nms)
+    rec = {"config": f"{name}-face 640x640 batch {B} + batched NMS", "letterbox_ms": round(t_pre * 1e3, 3),
+           "forward_decode_ms": round(t_fwd * 1e3, 3), "nms_ms": round(t_nms * 1e3, 3),
+           "img_per_s": round(rate, 1), "frac_of_roofline": round(rate / ROOF_YOLO_IMG_S[name], 4),
+           "cand_per_img": round(cand, 1), "dets_per_img": round(float(cnt.float().mean()), 2),
+           "overflow": int(over.sum()), "algorithmic_GBps_forward": round(alg / t_fwd / 1e9, 1), "n_ops": plan.n_ops}
+    print(json.dumps(rec), file=sys.stderr, flush=True)
+    return rec
 
 
-def yolo_to_embed(dev, B=256, faces_per_frame=4.0):
+def yolo_to_embed(dev, B=256, faces_per_frame=4.0, cands=(2, 4, 6, 8, 12, 16), two_streams=True):
     """BASELINE configs[3]: YOLOv5s-face detect -> fmt = 1 crops -> Mobile-FaceNet 112x112, ~1024 crops per step
     (the candidate count is searched off the clock so that ~faces_per_frame boxes per frame survive NMS and the area
     filter)."""
@@ -60,7 +67,7 @@ def yolo_to_embed(dev, B=256, faces_per_frame=4.0):
     calib = frames                      # calibrate the candidate count on the measured batch itself (off the clock)
     emb = W.build_embedder(dev)
     best, table = None, []
-    for cand in (2, 4, 6, 8, 12, 16):
+    for cand in cands:
         det = W.build_yolo_detector(dev, calib, "yolov5s", cand_per_frame=cand)
         pipe = FacePipeline(det, emb, None, max_faces_per_frame=64)
         n = pipe.step(frames)["n_faces"] / float(B)
@@ -70,6 +77,14 @@ def yolo_to_embed(dev, B=256, faces_per_frame=4.0):
     _, cand, pipe = best
     n = pipe.step(frames)["n_faces"]
     t = timeit(lambda: pipe.step(frames))
+    # frames at 19.2 k img/s + crops at 310 k crops/s = the step's time at the roofline
+    t_roof = B / ROOF_YOLO_IMG_S["yolov5s"] + n / ROOF_MFN_CROPS_S
+    rec = {"config": f"yolov5s-face detect -> Mobile-FaceNet 112x112, batch {B} frames", "ms": round(t * 1e3, 3),
+           "crops_per_step": n, "cand_per_frame": cand, "search": table, "frames_per_s": round(B / t, 1),
+           "crops_per_s": round(n / t, 1), "frac_of_roofline": round(t_roof / t, 4)}
+    if not two_streams:
+        print(json.dumps(rec), file=sys.stderr, flush=True)
+        return rec
     # the same steps software-pipelined on two streams (FacePipeline.step_overlapped: the detector of batch k + 1 beside the
     # embedder of batch k), as bench.py runs configs[1]
     det2 = W.build_yolo_detector(dev, calib, "yolov5s", cand_per_frame=cand)
@@ -85,10 +100,10 @@ def yolo_to_embed(dev, B=256, faces_per_frame=4.0):
     overlapped(10)
     torch.cuda.synchronize()
     t2 = (time.perf_counter() - t0) / 10
-    print(json.dumps({"config": f"yolov5s-face detect -> Mobile-FaceNet 112x112, batch {B} frames", "ms": round(t * 1e3, 3),
-                      "crops_per_step": n, "cand_per_frame": cand, "search": table, "frames_per_s": round(B / t, 1),
-                      "crops_per_s": round(n / t, 1), "two_stream_ms": round(t2 * 1e3, 3),
-                      "two_stream_frames_per_s": round(B / t2, 1), "two_stream_crops_per_step": n2}), flush=True)
+    rec.update({"two_stream_ms": round(t2 * 1e3, 3), "two_stream_frames_per_s": round(B / t2, 1),
+                "two_stream_crops_per_step": n2, "two_stream_frac_of_roofline": round(t_roof / t2, 4)})
+    print(json.dumps(rec), file=sys.stderr, flush=True)
+    return rec
 
 
 def embed_1024(dev):
@@ -97,8 +112,10 @@ def embed_1024(dev):
     plan.input.normal_()
     t = timeit(lambda: plan.run())
     alg = sum(plan.algorithmic_bytes(i) for i in range(plan.n_ops))
-    print(json.dumps({"config": "Mobile-FaceNet 112x112 batch 1024 crops", "ms": round(t * 1e3, 3),
-                      "crops_per_s": round(1024 / t, 1), "algorithmic_GBps": round(alg / t / 1e9, 1)}), flush=True)
+    rec = {"config": "Mobile-FaceNet 112x112 batch 1024 crops", "ms": round(t * 1e3, 3), "crops_per_s": round(1024 / t, 1),
+           "frac_of_roofline": round(1024 / t / ROOF_MFN_CROPS_S, 4), "algorithmic_GBps": round(alg / t / 1e9, 1)}
+    print(json.dumps(rec), file=sys.stderr, flush=True)
+    return rec
 
 
 def cosine(dev, M, Nr=10000, D=512):
@@ -108,22 +125,38 @@ def cosine(dev, M, Nr=10000, D=512):
     ginv, rinv = S.row_inv_norm(G), S.row_inv_norm(R)
     r3 = S.split3_rows(R)      # the reference set is split once (csrc/split.h), like its inverse norms
     t = timeit(lambda: S.cosine_filter(G, R, 0.3, ginv, rinv, r3=r3), n=3, warm=1)
-    print(json.dumps({"config": f"cosine filter {M} x {Nr} x {D}", "ms": round(t * 1e3, 2),
-                      "TFLOPs": round(2.0 * M * Nr * D / t / 1e12, 1), "pair_scores_per_s": round(M * Nr / t, 0)}),
-          flush=True)
+    tf = 2.0 * M * Nr * D / t / 1e12
+    rec = {"config": f"cosine filter {M} x {Nr} x {D}", "ms": round(t * 1e3, 2), "TFLOPs": round(tf, 1),
+           "frac_of_roofline": round(tf / ROOF_FP32_MFMA_TF, 4), "pair_scores_per_s": round(M * Nr / t, 0)}
+    print(json.dumps(rec), file=sys.stderr, flush=True)
+    return rec
+
+
+def other_configs(dev):
+    """The short legs bench.py appends to its result line (`other_configs`): BASELINE configs[2], configs[3], the embedder
+    at batch 1024 and the configs[4] per-GPU shard, each with its fraction of SURVEY 8(d)'s roofline."""
+    out = []
+    for fn in (lambda: yolo("yolov5n", dev), lambda: yolo_to_embed(dev, cands=(4, 6), two_streams=False),
+               lambda: embed_1024(dev), lambda: cosine(dev, 125_000)):
+        out.append(fn())
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     which = sys.argv[1:] or ["yolov5n", "yolov5s", "c4", "embed", "cosine"]
+    recs = []
     if "yolov5n" in which:
-        yolo("yolov5n", dev)
+        recs.append(yolo("yolov5n", dev))
     if "yolov5s" in which:
-        yolo("yolov5s", dev)
+        recs.append(yolo("yolov5s", dev))
     if "c4" in which:
-        yolo_to_embed(dev)
+        recs.append(yolo_to_embed(dev))
     if "embed" in which:
-        embed_1024(dev)
+        recs.append(embed_1024(dev))
     if "cosine" in which:
-        cosine(dev, 125_000)
-        cosine(dev, 1_000_000)
+        recs.append(cosine(dev, 125_000))
+        recs.append(cosine(dev, 1_000_000))
+    for r in recs:
+        print(json.dumps(r), flush=True)

@@ -16,6 +16,7 @@ canvas = torch.empty((n, 112, 112, 4), device=dev)
 for mode in ("", "1", "", "1"):
     if mode: os.environ["FP_RESIZE_PER_PIXEL"] = "1"
     else: os.environ.pop("FP_RESIZE_PER_PIXEL", None)
+    lib.fp_debug_reload_env()
     for _ in range(3):
         lib.fp_resize_normalize(L.ptr(frames), 256, 576, 1024, L.ptr(it), n, L.ptr(canvas), 112, 112, 4, L.ptr(lut), 0, 0, L.current_stream(dev))
     torch.cuda.synchronize()
