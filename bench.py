@@ -534,10 +534,13 @@ def run_pipeline(args):
     arith = None
     if rank == 0:
         arith = {"mobilefacenet_depth_wise": args.mfma,
-                 "note": "bf16x6: fp32 operands split EXACTLY into three bf16 pieces (w == h + m + l), six of the nine "
-                         "products on v_mfma_f32_16x16x32_bf16, fp32 accumulation; dropped terms <= 2^-23 of a product "
-                         "(one fp32 rounding); parity tests use the same bounds as for the fp32-MFMA kernels and check "
-                         "against fp64 that the error is not above the fp32 oracle's own; everything else fp32 throughout"}
+                 "note": "bf16x6: fp32 operands split EXACTLY into three bf16 pieces by round-to-nearest cuts (w == h + m + l, "
+                         "|m| <= 2^-8 |w|, |l| <= 2^-16 |w|), six of the nine products on v_mfma_f32_16x16x32_bf16, fp32 "
+                         "accumulation; the three dropped products are < 2^-22.99 of a product (one fp32 rounding unit) and carry "
+                         "either sign; measured against fp64 on adversarial operands (all-ones mantissas, rounding ties, "
+                         "all-positive rows, K up to 1152: tests/test_gpu_parity.py test_split_gemms_adversarial_vs_fp64) the "
+                         "error is below the k-ordered fp32 fmaf chain's, or 2^-23 of sum |a b| where that chain is exact; "
+                         "everything else fp32 throughout"}
         if world == 1 and args.mfma == "bf16x6" and not args.no_fp32_leg:
             # (both legs: single stream, every step self-contained -- FacePipeline.step -- so that they compare with each other)
             for k in range(2):
@@ -697,7 +700,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mfma", choices=["bf16x6", "fp32"], default="bf16x6",
                     help="matrix arithmetic of the Mobile-FaceNet Depth_Wise blocks: bf16x6 = fp32 operands split exactly into "
-                         "three bf16 pieces, six products, fp32 accumulation (csrc/split.h; as accurate as the fp32 fmaf chain); "
+                         "three bf16 pieces (round-to-nearest cuts), six products, fp32 accumulation (csrc/split.h); "
                          "fp32 = every GEMM on the fp32 MFMA (rounds 1-3)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs of BASELINE configs[2], [3], the batch-1024 embedder and the configs[4] shard that "

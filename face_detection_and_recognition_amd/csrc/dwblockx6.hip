@@ -546,14 +546,12 @@ __global__ __launch_bounds__(256, 3) void dwblock_x6q_kernel(DwbX6Args p) {
           a0 = __builtin_fmaf(x2, tap[8], a0);
           float v = __builtin_fmaf(a0, dsc, dbi);
           v = __builtin_fmaf(__builtin_fminf(v, 0.f), dsl, v);
-          const unsigned hu = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
-          const float r1 = v - __builtin_bit_cast(float, hu);
-          const unsigned mu = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-          const float r2 = r1 - __builtin_bit_cast(float, mu);
-          unsigned short* d = dst + (i - 2) * 7 * 32;   // upper halves: hipcc emits ds_write_b16_d16_hi
-          d[0] = (unsigned short)(hu >> 16);
-          d[K::DPL] = (unsigned short)(mu >> 16);
-          d[2 * K::DPL] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+          unsigned hu, mu, lu;
+          fp_split_one(v, hu, mu, lu);
+          unsigned short* d = dst + (i - 2) * 7 * 32;
+          d[0] = (unsigned short)hu;
+          d[K::DPL] = (unsigned short)mu;
+          d[2 * K::DPL] = (unsigned short)lu;
         }
         if (i >= 1 && i < 8) {
           a1 = __builtin_fmaf(x0, tap[3], a1);

@@ -3,20 +3,27 @@
 // gfx950 has no TF32 / xf32 MFMA, and its fp32 MFMA runs at the fp32 VECTOR rate on the vector ALU (64 FLOP/clk/SIMD,
 // 157 TFLOP/s; DESIGN finding 18: it does not even overlap with VALU work), while v_mfma_f32_16x16x32_bf16 delivers
 // 1024 FLOP/clk/SIMD on the matrix core beside the VALU.  An fp32 number has 24 significant bits = three bf16 pieces
-// of 8 bits each, cut by TRUNCATION of the sign-magnitude bit pattern:
-//     h = x & 0xffff0000,  m = (x - h) & 0xffff0000,  l = (x - h) - m        x == h + m + l  EXACTLY
-// (both subtractions are exact in fp32; the last remainder has at most 8 significant bits).  A product a*b of two
-// fp32 numbers is then the sum of nine bf16 x bf16 products (each exact in the MFMA's fp32 accumulator); the kernels
-// keep the six whose weight is >= 2^-16 of the product,
+// of 8 bits each, cut by ROUND-TO-NEAREST-EVEN conversions (v_cvt_pk_bf16_f32, one instruction per two values):
+//     h = bf16(x),  m = bf16(x - h),  l = bf16((x - h) - m)        x == h + m + l  EXACTLY
+// Both subtractions are exact in fp32 (Sterbenz-type: x - h is the rounding error of an 8-bit rounding of a 24-bit
+// number, it has at most 16 significant bits; the second remainder at most 8, so the last conversion does not round), and
+//     |m| <= 2^-8 |x| (1 + 2^-8),   |l| <= 2^-16 |x| (1 + 2^-8)      (half an ulp of an 8-bit significand, twice).
+// A product a*b of two fp32 numbers is then the sum of nine bf16 x bf16 products (each exact in the MFMA's fp32
+// accumulator); the kernels keep the six whose weight is >= 2^-16 of the product,
 //     ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm),
-// and drop am*bl + al*bm + al*bl <= 2^-23 |a*b| -- the size of ONE fp32 rounding.  Accumulation is fp32 as before.
-// Measured through the whole Mobile-FaceNet (tests/test_split_precision.py, fp64 as the truth): max |embedding error|
-// 2.1e-7 for this scheme against 3.3e-7 for the fp32 fmaf chain; a two-piece split (three products) gives 3.5e-5 and
-// is NOT used.  Cost: 6 MFMAs of ~18 cycles per 16x16x32 block (tools/lab/coexec_bf16_lab.hip) against 16 of 32 cycles
-// (16x16x4 f32) = 4.7x fewer matrix cycles, and each MFMA holds the SIMD's issue port for only ~8 of them: the VALU of
-// the partner wave gets about two instructions in per MFMA (v_fma_f32 8.7 cycles beside MFMAs, 6.3 alone; v_pk_fma_f32
-// 22.5 against 9.0).
-// Weights are split once on the host (plan.py split3_bf16); activations in registers where they are produced.
+// and drop am*bl + al*bm + al*bl, whose magnitude is <= (2 * 2^-24 + 2^-32)(1 + 2^-7) |a*b| < 2^-22.99 |a*b|: ONE fp32
+// rounding unit, and -- because the remainders of a rounding carry either sign -- not a one-sided bias.  (Rounds 1-3 cut
+// the pieces by TRUNCATION: |m| < 2^-7, |l| < 2^-15, dropped terms < 2^-21 |a*b| and always of the product's sign; the
+// round-to-nearest cut costs the same number of VALU instructions, 9 per pair against 11.)  Accumulation is fp32.
+// Values within 2^-8 of FLT_MAX would round to a bf16 infinity; activations and weights are nowhere near.
+// Measured through the whole Mobile-FaceNet (tests/test_split_precision.py, fp64 as the truth): the embedding error of
+// this scheme is not above the fp32 fmaf chain's; adversarial operands (all-ones mantissas, same-sign rows, K up to
+// 1152) in tests/test_gpu_parity.py (test_split_gemms_adversarial_vs_fp64).  A two-piece split (three products) gives
+// 3.5e-5 and is NOT used.  Cost: 6 MFMAs of ~18 cycles per 16x16x32 block (tools/lab/coexec_bf16_lab.hip) against 16
+// of 32 cycles (16x16x4 f32) = 4.7x fewer matrix cycles, and each MFMA holds the SIMD's issue port for only ~8 of them:
+// the VALU of the partner wave gets about two instructions in per MFMA.
+// Weights are split once on the host (plan.py split3_bf16, the same roundings); activations in registers where they are
+// produced.
 #pragma once
 #include "common.h"
 
@@ -24,20 +31,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// (hi half of b) : (hi half of a)  ->  one dword holding bf16(a) in its low half, bf16(b) in its high half (truncation)
-__device__ __forceinline__ unsigned fp_pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> one dword holding bf16(a) in its low half, bf16(b) in its high half (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned fp_pack_bf16_rn(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 // Two floats -> their three bf16 planes, each plane a dword (element 0 in the low half).
 __device__ __forceinline__ void fp_split_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
-  const float r0 = v0 - __builtin_bit_cast(float, u0 & 0xffff0000u);
-  const float r1 = v1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-  const unsigned a0 = __builtin_bit_cast(unsigned, r0), a1 = __builtin_bit_cast(unsigned, r1);
-  const float s0 = r0 - __builtin_bit_cast(float, a0 & 0xffff0000u);
-  const float s1 = r1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
-  h = fp_pack_hi16(u0, u1);
-  m = fp_pack_hi16(a0, a1);
-  l = fp_pack_hi16(__builtin_bit_cast(unsigned, s0), __builtin_bit_cast(unsigned, s1));
+  h = fp_pack_bf16_rn(v0, v1);
+  const float r0 = v0 - __builtin_bit_cast(float, h << 16);
+  const float r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = fp_pack_bf16_rn(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16);
+  const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = fp_pack_bf16_rn(s0, s1);      // exact: the second remainder has at most 8 significant bits
+}
+
+// One float -> its three bf16 pieces (bit patterns in the low 16 bits).
+__device__ __forceinline__ void fp_split_one(float v, unsigned& h, unsigned& m, unsigned& l) {
+  h = fp_pack_bf16_rn(v, v) & 0xffffu;
+  const float r = v - __builtin_bit_cast(float, h << 16);
+  m = fp_pack_bf16_rn(r, r) & 0xffffu;
+  const float s = r - __builtin_bit_cast(float, m << 16);
+  l = fp_pack_bf16_rn(s, s) & 0xffffu;
 }
 
 // Eight consecutive k of one row (two float4) -> the three 8 x bf16 MFMA fragments.

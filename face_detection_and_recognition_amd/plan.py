@@ -131,16 +131,23 @@ def pack_dw_weight(w, c_phys):
     return out.reshape(-1)
 
 
+def _bf16_rn_bits(x):
+    """fp32 array -> uint32 bit patterns of bf16(x) << 16 (round to nearest even; no NaN / inf handling -- weights are finite)."""
+    u = x.view(np.uint32)
+    return (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+
+
 def split3_bf16(w):
-    """The exact three-way bf16 split of fp32 values (csrc/split.h): w == h + m + l with h, m, l the sign-magnitude
-    truncations to 8 significant bits.  Returns uint16 [3, ...] (the top halves of the three fp32 bit patterns)."""
+    """The exact three-way bf16 split of fp32 values (csrc/split.h): h = bf16(w), m = bf16(w - h), l = bf16(w - h - m), every
+    conversion round-to-nearest-even, every subtraction exact, w == h + m + l.  Returns uint16 [3, ...] (the bf16 bit
+    patterns of the three pieces)."""
     w = np.ascontiguousarray(w, dtype=np.float32)
-    mask = np.uint32(0xFFFF0000)
-    h = w.view(np.uint32) & mask
+    h = _bf16_rn_bits(w)
     r = w - h.view(np.float32)
-    m = r.view(np.uint32) & mask
+    m = _bf16_rn_bits(r)
     r2 = r - m.view(np.float32)
-    l = r2.view(np.uint32) & mask
+    l = _bf16_rn_bits(r2)
+    assert np.array_equal(l.view(np.float32), r2), "third piece is not exact"
     assert np.array_equal(h.view(np.float32) + m.view(np.float32) + l.view(np.float32), w)
     return np.stack([h >> 16, m >> 16, l >> 16]).astype(np.uint16)
 

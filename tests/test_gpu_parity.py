@@ -1039,6 +1039,129 @@ def test_split_kernels_keep_fp32_dynamic_range(dev, scale):
     assert np.abs(got - want64).max() <= 2.0 * np.abs(want - want64).max() + 2e-7 * np.abs(want64).max()
 
 
+def _adversarial_f32(rng, shape, kind):
+    """Operands that make the split's dropped terms as large and as one-sided as they get.
+    "ones": every mantissa all ones (0x..7fffff), all positive, magnitudes within a factor of 4 -- the pieces m and l sit at
+    their bounds and every dropped product has the sign of the product it belongs to under a truncation split;
+    "ties": mantissas on / next to the rounding ties of both cuts, all positive;  "positive": uniform in [0.5, 1)."""
+    n = int(np.prod(shape))
+    if kind == "positive":
+        return rng.uniform(0.5, 1.0, shape).astype(np.float32)
+    if kind == "ones":
+        mant = np.full(n, 0x7FFFFF, np.uint32)
+    else:
+        mant = rng.choice(np.array([0x007FFF, 0x008000, 0x008001, 0x00807F, 0x0080FF, 0x7F7F7F, 0x7F8080], np.uint32), n)
+    expo = rng.integers(125, 127, n).astype(np.uint32)              # [0.25, 1)
+    return ((expo << np.uint32(23)) | mant).view(np.float32).reshape(shape)
+
+
+def _fmaf_chain(a, b):
+    """a (M, K) @ b (K, N) as the k-ordered fp32 fmaf chain the fp32-MFMA kernels compute (acc = fl32(acc + a_k * b_k), the
+    product exact): the arithmetic the split kernels replace.  fp64 holds acc + a*b exactly enough (24 + 48 bits)."""
+    acc = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    for k in range(a.shape[1]):
+        acc = (acc.astype(np.float64) + a64[:, k, None] * b64[None, k, :]).astype(np.float32)
+    return acc
+
+
+@pytest.mark.parametrize("kind", ["ones", "ties", "positive"])
+@pytest.mark.parametrize("k", [512, 1152])
+def test_split_gemms_adversarial_vs_fp64(dev, k, kind):
+    """the bf16x6 kernels on operands chosen against them -- all-ones mantissas, rounding ties, all-positive
+    rows (no cancellation: every dropped term and every rounding adds up), long K -- with fp64 as the truth and NO absolute
+    slack: errors are relative to sum_k |a_k b_k| and bounded in fp32 rounding units u = 2^-24.
+      * against the arithmetic the split replaces (the k-ordered fp32 fmaf chain of the fp32-MFMA kernels): max and rms error
+        not above twice the chain's -- or one rounding unit of the split, 2^-23, where the chain happens to be exact below
+        that ("ones": every product is the same number and the chain's partial sums are representable; the split kernel
+        then shows exactly what it loses: the hm + mh correction of a slab, 2^-24 of the slab, is below half an ulp of the
+        running sum);
+      * against the scheme's a-priori bound (split.h): dropped terms 2u + six fp32 additions per 32-k slab of half an ulp
+        each = (2 + 3 K / 32) u, which is below the fmaf chain's own a-priori bound K u;
+      * no drift: |mean signed error| <= 2^-23 (a truncation split drifts by -K * 2^-22 on these rows).
+    torch's CPU conv (blocked partial sums) is reported in the assertion messages; DESIGN section 4 holds the measured table."""
+    rng = np.random.default_rng(k + len(kind))
+    N, H, W, n = 2, 16, 16, 128
+    x = _adversarial_f32(rng, (N, k, H, W), kind)
+    w = _adversarial_f32(rng, (n, k, 1, 1), kind)
+    pb = PlanBuilder(N)
+    xb, ob = pb.new_buf(H, W, k), pb.new_buf(H, W, n)
+    pb.conv(xb.view(), w, ob.view())
+    plan = CompiledPlan(pb, dev)
+    assert plan.kernel_name(0).startswith("pwx6_kernel"), plan.kernel_name(0)
+    plan.buf_tensor(xb, N).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(ob, N)
+    out_t.fill_(float("nan"))
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.cpu().numpy().reshape(-1, n)                       # (pixels, cout), NHWC
+    a = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).reshape(-1, k)
+    b = np.ascontiguousarray(w.reshape(n, k).T)
+    exact = a.astype(np.float64) @ b.astype(np.float64)            # all terms positive: exact == sum |a_k b_k|
+    torch32 = F.conv2d(torch.from_numpy(x), torch.from_numpy(w)).permute(0, 2, 3, 1).reshape(-1, n).numpy()
+    u = 2.0 ** -24
+    r6, rc, rt = (np.abs(v - exact) / exact / u for v in (got, _fmaf_chain(a, b), torch32))
+    msg = {"x6 max/rms": (r6.max(), np.sqrt((r6 ** 2).mean())), "chain": (rc.max(), np.sqrt((rc ** 2).mean())),
+           "torch": (rt.max(), np.sqrt((rt ** 2).mean()))}
+    assert np.isfinite(got).all()
+    assert r6.max() <= max(2.0 * rc.max(), 2.0) * (1 + 1e-6), msg
+    assert np.sqrt((r6 ** 2).mean()) <= max(2.0 * np.sqrt((rc ** 2).mean()), 2.0) * (1 + 1e-6), msg
+    assert r6.max() <= 2.0 + 3.0 * k / 32 < k, msg
+    bias = ((got - exact) / exact).mean() / u
+    assert abs(bias) <= 2.0 * (1 + 1e-6), (bias, msg)
+
+    # cosine_x6_kernel on rows of the same kind (D = k): scores near 1, nothing cancels
+    M, Nr = 300, 200
+    G, R = _adversarial_f32(rng, (M, k), kind), _adversarial_f32(rng, (Nr, k), kind)
+    best6 = S.cosine_filter(torch.from_numpy(G).to(dev), torch.from_numpy(R).to(dev), 0.05, x6=True)[0].cpu().numpy()
+    best32 = S.cosine_filter(torch.from_numpy(G).to(dev), torch.from_numpy(R).to(dev), 0.05, x6=False)[0].cpu().numpy()
+    G64, R64 = G.astype(np.float64), R.astype(np.float64)
+    S64 = ((G64 / np.linalg.norm(G64, axis=1, keepdims=True)) @ (R64 / np.linalg.norm(R64, axis=1, keepdims=True)).T).max(1)
+    Gn, Rn = G / np.linalg.norm(G, axis=1, keepdims=True), R / np.linalg.norm(R, axis=1, keepdims=True)
+    cpu32 = (Gn @ Rn.T).max(1)                                       # the oracle's arithmetic (numpy fp32)
+    c6, c32, ccpu = (np.abs(v - S64).max() / u for v in (best6, best32, cpu32))   # scores in [0, 1]: sum |a_k b_k| = 1 after the norms
+    assert c6 <= max(2.0 * c32, 4.0) and c6 <= max(2.0 * ccpu, 4.0), (c6, c32, ccpu)   # (two more roundings: the inverse norms)
+
+
+@pytest.mark.parametrize("cin,hw", [(128, 14), (64, 28), (128, 7)])
+def test_dwblock_x6_adversarial_vs_fp64(dev, cin, hw):
+    """The whole-Depth_Wise split kernel (dwblock_x6_kernel / dwblock_x6q_kernel) on all-positive, all-ones-mantissa weights
+    and inputs (both GEMMs, K = cin and 2 cin, see no cancellation; BN is the identity, PReLU never fires), against the fp64
+    oracle with no absolute slack: not above twice the fp32 oracle's own error."""
+    rng = np.random.default_rng(77 + hw)
+    n = 5
+    blk = Depth_Wise(cin, cin, residual=True, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=2 * cin)
+    sd = {k_: torch.as_tensor(v).clone() for k_, v in synth_state_dict(blk.state_dict(), 1).items()}
+    for k_, v in sd.items():
+        if k_.endswith("conv.weight"):
+            fan = v[0].numel()
+            sd[k_] = torch.from_numpy(_adversarial_f32(rng, tuple(v.shape), "ones") * np.float32(2.0 / fan))
+        elif k_.endswith("bn.weight") or k_.endswith("running_var"):
+            sd[k_] = torch.ones_like(v)
+        elif k_.endswith("bn.bias") or k_.endswith("running_mean"):
+            sd[k_] = torch.zeros_like(v)
+    blk.load_state_dict(sd)
+    x = _adversarial_f32(rng, (n, cin, hw, hw), "ones")
+    pb = PlanBuilder(n)
+    inp = pb.new_buf(hw, hw, cin)
+    y = blk.emit(pb, inp.view())
+    plan = CompiledPlan(pb, dev)
+    assert plan.n_ops == 1 and plan.kernel_name(0).startswith("dwblock_x6"), plan.kernel_name(0)
+    plan.buf_tensor(inp, n).copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+    out_t = plan.buf_tensor(y, n)
+    out_t.fill_(float("nan"))
+    plan.run()
+    torch.cuda.synchronize()
+    got = out_t.permute(0, 3, 1, 2).cpu().numpy()
+    ref = mobilefacenet_ref._depth_wise(sd, "", torch.from_numpy(x), 1, True).numpy()
+    ref64 = mobilefacenet_ref._depth_wise({k_: (v.double() if v.is_floating_point() else v) for k_, v in sd.items()}, "",
+                                          torch.from_numpy(x).double(), 1, True).numpy()
+    assert np.isfinite(got).all() and (ref64 > 0).all()
+    u = 2.0 ** -24
+    e6, e32 = (np.abs(got - ref64) / ref64).max() / u, (np.abs(ref - ref64) / ref64).max() / u
+    assert e6 <= max(2.0 * e32, 4.0), (e6, e32)     # two split GEMMs in sequence: 2 x 2^-23 where the fp32 oracle is exact below that
+
+
 def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev):
     """The reference's own Mobile-FaceNet output (tests/golden/mobilefacenet_forward.npz) through three plans (batch
     capacity 64, run on the golden's 4 images): (a) the default -- all twelve stride-1 blocks as the
@@ -1812,3 +1935,100 @@ def test_yolo_pipeline_matches_oracle_end_to_end(dev):
     assert len(dets) == len(ref) and len(ref) > 0
     np.testing.assert_allclose(dets[:, :4] * 640, ref[:, :4], rtol=0, atol=2e-2)
     np.testing.assert_allclose(dets[:, 4], ref[:, 4], rtol=0, atol=1e-4)
+
+
+def test_full_size_config2_yolov5n_256_frames_sampled_vs_oracle(dev):
+    """BASELINE configs[2] at its full size: YOLOv5n-face on 256 synthetic 576 x 1024 frames,
+    letterboxed to 640 x 640 inside the stem, Detect decode, batched NMS -- the plan, kernel selection (batch-dependent:
+    pwx6 tile forms, conv3 thresholds) and arena of the measured config, not of a 1-4 frame test.  Three sampled frames
+    are re-done by the oracle network (y5/models/yolo.py:177-198): decoded rows within 1e-4 of the row scale (boxes: 1e-4
+    of the 640-pixel image; scores 1e-4); the kept rows of every sampled frame are EXACT against the oracle NMS
+    (y5/utils/general.py:370-453) run on the device's own decoded predictions."""
+    from face_detection_and_recognition_amd import workload as W
+    from face_detection_and_recognition_amd.modules.yolov5_face import nms_face_device, preprocess_batch
+    from face_detection_and_recognition_amd.modules.yolov5_face.yolo import SPECS
+    from oracle import yolo_ref
+    B = 256
+    frames = W.make_frames(B, dev, seed=5)
+    det = W.build_yolo_detector(dev, W.make_frames(16, dev, seed=6), "yolov5n", cand_per_frame=80)
+    plan = preprocess_batch(det.net, frames, (640, 640))
+    names = [plan.kernel_name(i) for i in range(plan.n_ops)]
+    assert plan.N == B and names[0].startswith("ystem_kernel") and any(nm.startswith("pwx6_kernel") for nm in names)
+    z = det.net.run_plan(plan)
+    out, cnt, keep, over = nms_face_device(z, 0.4, 0.5)
+    torch.cuda.synchronize()
+    assert z.shape == (B, 25200, 16) and bool(torch.isfinite(z).all()) and int(over.sum()) == 0
+    cnt_h = cnt.cpu().numpy()
+    cand = ((z[..., 4] > 0.4) & (z[..., 4] * z[..., 15] > 0.4)).sum(1).cpu().numpy()
+    assert 30 < cand.mean() < 300 and np.all(cnt_h <= cand) and cnt_h.mean() >= 1
+    sd = {k: v.detach().cpu() for k, v in det.net.state_dict().items()}
+    for fi in (0, 131, 255):
+        f = frames[fi].cpu().numpy()
+        lb = image_ref.pad_resize_image(f[..., ::-1], (640, 640))
+        x = torch.from_numpy(image_ref.yolo_lut()[lb]).permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            z_ref, _ = yolo_ref.forward(SPECS["yolov5n"], sd, x)
+        zi, zr = z[fi].cpu().numpy(), z_ref[0].numpy()
+        assert rel_err(zi, zr) < 1e-4
+        np.testing.assert_allclose(zi[:, :4], zr[:, :4], rtol=0, atol=1e-4 * 640)          # boxes: pixels of the 640 canvas
+        np.testing.assert_allclose(zi[:, 5:15], zr[:, 5:15], rtol=1e-4, atol=1e-4 * 640)     # landmarks (linear heads)
+        np.testing.assert_allclose(zi[:, [4, 15]], zr[:, [4, 15]], rtol=0, atol=1e-4)      # objectness, class score
+        ref_out, ref_idx = yolo_ref.non_max_suppression_face(zi[None], 0.4, 0.5)
+        k = cnt_h[fi]
+        assert k == len(ref_idx[0]) and k >= 1
+        np.testing.assert_array_equal(keep[fi, :k].cpu().numpy(), ref_idx[0].numpy())       # kept row indices: exact
+        np.testing.assert_array_equal(out[fi, :k].cpu().numpy(), ref_out[0].numpy())
+
+
+def test_full_size_config3_yolov5s_to_1024_crops_sampled_vs_oracle(dev):
+    """BASELINE configs[3] at its full size: YOLOv5s-face on 256 frames -> NMS -> fmt = 1 crops -> Mobile-FaceNet on >= 1024
+    crops in ONE embedder run (a 1280-crop arena; Depth_Wise kernel choice and tile rounds of that batch), through
+    FacePipeline as bench.py's `other_configs` leg runs it.  Sampled frames: boxes / crop rectangles exact against the oracle
+    post-processing on the device's decoded predictions, the frame's embeddings within 1e-4 of the oracle Mobile-FaceNet
+    on the oracle's crops; whole batch: unit-norm embeddings, rows ordered by frame."""
+    from face_detection_and_recognition_amd import workload as W
+    from face_detection_and_recognition_amd.modules.yolov5_face import preprocess_batch
+    from face_detection_and_recognition_amd.pipeline import FacePipeline
+    from oracle import yolo_ref
+    B = 256
+    frames = W.make_frames(B, dev, seed=5)
+    emb = W.build_embedder(dev)
+    n, pipe, out = 0, None, None
+    for cand in (6, 8, 12):                         # the candidate count that leaves >= 1024 crops after NMS + area filter
+        det = W.build_yolo_detector(dev, frames, "yolov5s", cand_per_frame=cand)
+        pipe = FacePipeline(det, emb, None, max_faces_per_frame=64)
+        out = pipe.step(frames)
+        n = out["n_faces"]
+        if n >= 1024:
+            break
+    torch.cuda.synchronize()
+    assert 1024 <= n <= 4096, n
+    eplan = pipe.emb_plan
+    assert eplan.N >= n and eplan.N % 256 == 0 and L.OP_DWBLOCK in [eplan.ops[i].kind for i in range(eplan.n_ops)]
+    info, items, got_emb = out["info"].cpu().numpy(), out["items"].cpu().numpy(), out["emb"].cpu().numpy()
+    assert got_emb.shape == (n, 512) and np.isfinite(got_emb).all()
+    np.testing.assert_allclose(np.linalg.norm(got_emb, axis=1), 1.0, atol=1e-5)
+    assert (np.diff(info[:, 0]) >= 0).all() and info[:, 0].max() < B
+    plan = preprocess_batch(det.net, frames, det.input_size)
+    z = det.net.run_plan(plan)
+    sd_emb = {k: v.detach().cpu() for k, v in emb.state_dict().items()}
+    worst, checked = 0.0, 0
+    for fi in (0, 77, 200, 255):
+        f = frames[fi].cpu().numpy()
+        kept, _ = yolo_ref.non_max_suppression_face(z[fi:fi + 1].cpu().numpy(), 0.4, 0.5)
+        boxes, confs, areas = yolo_ref.get_bboxes_confs_areas(kept[0].numpy(), det.det_thres, det.bbox_area_thres,
+                                                              (1024, 576), (640, 640))
+        mine = np.nonzero(info[:, 0] == fi)[0]
+        assert len(mine) == len(boxes), (fi, len(mine), len(boxes))
+        np.testing.assert_array_equal(info[mine, 1:5], boxes)
+        np.testing.assert_array_equal(info[mine, 5], confs)
+        for j, box in enumerate(boxes):
+            crop, (x, y, xw, yh) = image_ref.crop_face(f, box)
+            assert tuple(items[mine[j], :5]) == (fi, x, y, xw - x, yh - y)
+            face = image_ref.mfn_lut()[image_ref.resize_bilinear_u8(crop, (112, 112))]
+            xin = torch.from_numpy(np.ascontiguousarray(face.transpose(2, 0, 1))).unsqueeze(0)
+            with torch.no_grad():
+                er = mobilefacenet_ref.forward(sd_emb, xin)[0].numpy()
+            worst = max(worst, float(np.abs(got_emb[mine[j]] - er).max()))
+            checked += 1
+    assert checked >= 4 and worst < 1e-4, (checked, worst)
