@@ -30,7 +30,13 @@ class FacePipeline:
     """detector: a BlazeFaceModel or YOLOV5FaceModel (HIP); embedder: a HIP MobileFaceNet;
     reference: (Nr, E) CUDA tensor of reference embeddings for the cosine filter (or None)."""
 
-    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=8, two_streams=False):
+    # embed(): a batch a little above a multiple of ROUND_CROPS crops is run as that multiple + the remainder on a side stream
+    ROUND_CROPS = 512     # crops whose tiles fill whole rounds of workgroups in every Depth_Wise kernel (2 / 4 / 7 tiles per crop, 512 slots)
+    TAIL_MAX = 96         # largest remainder worth splitting off (measured: tools/lab/embed_split_probe.py)
+    TAIL_CAP = 128        # capacity of the remainder's plan
+
+    def __init__(self, detector, embedder, reference=None, tau=0.3, max_faces_per_frame=8, bucket=8, two_streams=False,
+                 split_tail=True):
         self.det = detector
         self.emb = embedder
         self.tau = float(tau)
@@ -42,6 +48,8 @@ class FacePipeline:
         # k + 1 (the split-MFMA embedder kernels are matrix-core bound, the BlazeFace kernels vector-ALU / HBM bound, and
         # every kernel's last, partly empty round of workgroups is filled by the other stream's work)
         self.emb_stream = torch.cuda.Stream(device=self.dev) if two_streams else None
+        self.split_tail = bool(split_tail)
+        self.tail_stream = torch.cuda.Stream(device=self.dev) if split_tail else None
         net = getattr(detector, "net", None)
         self._co_net = net if hasattr(net, "co_scheduled") else None     # BlazeFace: no whole-CU ops beside the embedder's kernels
         self.set_reference(reference)
@@ -94,11 +102,41 @@ class FacePipeline:
         self._emb_cap = cap
         plan = self.emb.plan_for(cap, n_run=n_pad)
         self.emb_key, self.emb_n_pad = (cap, n_pad), n_pad     # the plan itself stays owned by the embedder's LRU cache
+        main = n_pad // self.ROUND_CROPS * self.ROUND_CROPS
+        if self.split_tail and main and 0 < n_pad - main <= self.TAIL_MAX and main < n_faces:
+            return self._embed_split(frames, items, n_faces, n_pad, main, plan)
         crops_to_input(frames, items, n_faces, plan.input, self.lut)
         if n_pad > n_faces:
             plan.input[n_faces:n_pad].zero_()    # padding crops: defined inputs (every op is per-image, their rows are dropped)
         plan.run(n=n_pad)
         return plan.out[:n_faces]
+
+    def _embed_split(self, frames, items, n_faces, n_pad, main, plan):
+        """~528 crops are 1056 band tiles of a 14 x 14 Depth_Wise kernel on 512 workgroup slots: two full rounds and a third
+        with 32 tiles, in EVERY launch (28 x 28: 2112 tiles, 56 x 56: 3696) -- the last 16 crops cost 0.25 ms of a 2.3 ms
+        forward.  The first `main` crops (whole rounds in every kernel) run on the current stream, the remainder as its own
+        small forward on a side stream beside them (its own plan / arena): 2.30 -> 2.16 ms alone on the GPU.  Every op is
+        per-image and kernels do not depend on the batch, so the rows are bit-identical to the one-run form
+        (tests: test_embedder_split_tail_is_bit_identical).  Returns a new (n_faces, E) tensor."""
+        rem, rem_pad = n_faces - main, n_pad - main
+        tail = self.emb.plan_for(self.TAIL_CAP, n_run=rem_pad)
+        cur = torch.cuda.current_stream(self.dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.tail_stream):
+            self.tail_stream.wait_event(ready)           # items / frames are complete (and the tail plan's previous consumer is done)
+            frames.record_stream(self.tail_stream)
+            items.record_stream(self.tail_stream)
+            crops_to_input(frames, items[main:], rem, tail.input, self.lut)
+            if rem_pad > rem:
+                tail.input[rem:rem_pad].zero_()
+            tail.run(n=rem_pad)
+            done = torch.cuda.Event()
+            done.record(self.tail_stream)
+        crops_to_input(frames, items, main, plan.input, self.lut)
+        plan.run(n=main)
+        cur.wait_event(done)
+        return torch.cat([plan.out[:main], tail.out[:rem]])
 
     @property
     def emb_plan(self):
