@@ -386,20 +386,30 @@ def run_pipeline(args):
     det_plan = det.net.last_plan
     emb_plan = pipe.emb_plan                   # one plan (arena capacity >= every step's face count), run on n_pad crops
     plans = [det_plan, emb_plan]
-    fam_ms = {}
+    fam_steps = {}
+    split_tail, pipe.split_tail = pipe.split_tail, False      # exclusive figures: nothing beside the op that is timed
     for k in range(N_BATCHES):
         probe = [p.new_timer() for p in plans]
         for p, t in zip(plans, probe):
             p._timing = (t, bytes([1] * p.n_ops))
         finish(pipe.step(batches[k % N_BATCHES], beside=args.overlap == 2))   # the plans of the timed steps, alone on the GPU
         torch.cuda.synchronize()
+        step_ms = {}
         for p, t in zip(plans, probe):
             p._timing = None
             ms0 = (ctypes.c_float * p.n_ops)()
             p.accumulate(t, ms0)
             p.destroy_timer(t)
             for i in range(p.n_ops):
-                fam_ms[p.kernel_name(i)] = fam_ms.get(p.kernel_name(i), 0.0) + ms0[i]
+                step_ms[p.kernel_name(i)] = step_ms.get(p.kernel_name(i), 0.0) + ms0[i]
+            if os.environ.get("BENCH_DEBUG_PROBE"):
+                sys.stderr.write(f"probe step {k} plan N={p.N} n_run={p.n_run}: " +
+                                 " ".join(f"{p.kernel_name(i).split('<')[0]}:{ms0[i] * 1e3:.0f}" for i in range(p.n_ops)) + "\n")
+        for name, v in step_ms.items():
+            fam_steps.setdefault(name, []).append(v)
+    pipe.split_tail = split_tail
+    # per family: the MEDIAN probe step x the number of probe steps (one disturbed launch must not pick the family)
+    fam_ms = {name: sorted(v)[len(v) // 2] * len(v) for name, v in fam_steps.items()}
     dom = max(fam_ms, key=fam_ms.get)
     probe_share = fam_ms[dom] / sum(fam_ms.values())
     probe_launches = sum(1 for p in plans for i in range(p.n_ops) if p.kernel_name(i) == dom) * N_BATCHES

@@ -21,7 +21,13 @@
 #include "common.h"
 
 #ifndef FP_PAIR_ABLATE
-#define FP_PAIR_ABLATE 0   // lab only (DESIGN finding 31): 1 no per-row barrier, 2 no MFMAs, 4 no depthwise FMAs, 8 no row loads / stores -- wrong results, timing only
+#define FP_PAIR_ABLATE 0   // lab only (DESIGN finding 31): 1 no per-row barrier, 2 no MFMAs, 4 no depthwise FMAs, 8 no row loads / stores,
+                           // 16 block 2 reads one ring row instead of three, 32 no LDS round trip of the output row, 64 depthwise taps not
+                           // re-read from LDS -- wrong results, timing only
+#endif
+#ifndef FP_PAIR_DIRECT_STORE
+#define FP_PAIR_DIRECT_STORE 1   // 1: y2 goes from the epilogue registers straight to global memory (32-byte pieces: a lane pair = 8 channels of
+                                 // one pixel; L2 merges the pieces of a line) instead of through the A tile: 6 LDS accesses per row less, 258 -> 250 us
 #endif
 
 namespace {
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
 #pragma unroll
             for (int ky = 0; ky < ((FP_PAIR_ABLATE & 4) ? 0 : 3); ++ky) {
               const int sl = ky == 0 ? s0 : ky == 1 ? s1 : s2;
-              const f32x4 w0 = *(const f32x4*)(wl1 + (ky * 3 + 0) * C);
-              const f32x4 w1 = *(const f32x4*)(wl1 + (ky * 3 + 1) * C);
-              const f32x4 w2 = *(const f32x4*)(wl1 + (ky * 3 + 2) * C);
+              const f32x4 w0 = (FP_PAIR_ABLATE & 64) ? dbias : *(const f32x4*)(wl1 + (ky * 3 + 0) * C);
+              const f32x4 w1 = (FP_PAIR_ABLATE & 64) ? dbias : *(const f32x4*)(wl1 + (ky * 3 + 1) * C);
+              const f32x4 w2 = (FP_PAIR_ABLATE & 64) ? dbias : *(const f32x4*)(wl1 + (ky * 3 + 2) * C);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 acc[q] += x[sl][q] * w0;
@@ -208,13 +214,13 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
             f32x4 acc[4] = {dbias, dbias, dbias, dbias};
 #pragma unroll
             for (int ky = 0; ky < ((FP_PAIR_ABLATE & 4) ? 0 : 3); ++ky) {
-              const float* rr = ring + ((yo + ky) & 3) * RROW + rg_dw;      // ring row of y1 row yo - 1 + ky
+              const float* rr = ring + ((yo + ((FP_PAIR_ABLATE & 16) ? 1 : ky)) & 3) * RROW + rg_dw;      // ring row of y1 row yo - 1 + ky
               f32x4 xv[6];
 #pragma unroll
               for (int j = 0; j < 6; ++j) xv[j] = *(const f32x4*)(rr + j * C);
-              const f32x4 w0 = *(const f32x4*)(wl2 + (ky * 3 + 0) * C);
-              const f32x4 w1 = *(const f32x4*)(wl2 + (ky * 3 + 1) * C);
-              const f32x4 w2 = *(const f32x4*)(wl2 + (ky * 3 + 2) * C);
+              const f32x4 w0 = (FP_PAIR_ABLATE & 64) ? dbias : *(const f32x4*)(wl2 + (ky * 3 + 0) * C);
+              const f32x4 w1 = (FP_PAIR_ABLATE & 64) ? dbias : *(const f32x4*)(wl2 + (ky * 3 + 1) * C);
+              const f32x4 w2 = (FP_PAIR_ABLATE & 64) ? dbias : *(const f32x4*)(wl2 + (ky * 3 + 2) * C);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 acc[q] += xv[q] * w0;
@@ -247,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
           {
             const float* spx = ring + ((yo + 1) & 3) * RROW + rg_ep;
             float* opx = &At[lr * C + 4 * h];
+            char* orow_g = outb + fp_uniform((long)yo * out_rb);
 #pragma unroll
             for (int j = 0; j < C / 8; ++j) {
               const f32x4 sv = *(const f32x4*)(spx + 8 * j) + *(const f32x4*)&Bp[32 + 8 * j + 4 * h];
@@ -255,10 +262,15 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
               for (int e = 0; e < 4; ++e) v[e] = (m0[4 * j + e] + m1[4 * j + e]) + sv[e];
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-              *(f32x4*)(opx + 8 * j) = v;
+              if (FP_PAIR_DIRECT_STORE | (FP_PAIR_ABLATE & 32)) {
+                // lane (lr, h): pixel x0 + lr, channels 8j + 4h .. + 3 -- with its partner lane (h ^ 1) a 32-byte piece
+                if (live) *(f32x4*)(orow_g + (unsigned)((lr * C + 4 * h + 8 * j) * 4)) = v;
+              } else {
+                *(f32x4*)(opx + 8 * j) = v;
+              }
             }
           }
-          if (live && !((FP_PAIR_ABLATE & 8) && yo > y0)) {
+          if (!FP_PAIR_DIRECT_STORE && !(FP_PAIR_ABLATE & 32) && live && !((FP_PAIR_ABLATE & 8) && yo > y0)) {
             char* orow_g = outb + fp_uniform((long)yo * out_rb);
 #pragma unroll
             for (int j = 0; j < 3; ++j) *(f32x4*)(orow_g + voff_out + j * 1024) = *(const f32x4*)&At[(lane + 64 * j) * 4];
