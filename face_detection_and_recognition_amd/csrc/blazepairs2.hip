@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256, 2) void blazepair_s2_kernel(BlazePairS2Args p)
   float* Bp = Ws + 2 * 10 * C;                             // [32] block 1, [64] block 2
   float* Rg = Bp + 96;                                     // [NSUB][4][RROW]
   float* Av = Rg + NSUB * RING;                            // 4 wave regions [32][LDT], then the output tiles (first: weight staging)
-  float* Ov = Av + 4 * 32 * LDT;
+  // (the region behind the A tiles, NSUB * NS2 * OTF floats, is weight staging only: y2 goes from the epilogue registers to
+  // global memory)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, h = lane >> 5;
@@ -74,7 +75,6 @@ __global__ __launch_bounds__(256, 2) void blazepair_s2_kernel(BlazePairS2Args p)
 
   const int sub = wv / NS, strip = wv - sub * NS;
   float* At = Av + wv * (32 * LDT);                        // A tile [32][LDT]
-  float* Ot = C2 > C ? Ov + (sub * NS2 + (strip < NS2 ? strip : 0)) * OTF : At;   // block 2's output tile [32][C2]
   float* ring = Rg + sub * RING;
   const int x0 = strip * 32;
   const bool b2wave = strip < NS2;                         // this wave makes output pixels 32 strip .. + 31 of a y2 row
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(256, 2) void blazepair_s2_kernel(BlazePairS2Args p)
   const int la = dw_lane ? lane : 0;
   const int g = la / C4, c4 = la - g * C4;
   const unsigned voff_in = (unsigned)((4 * g * C + 4 * c4) * 4);
-  const unsigned voff_out = (unsigned)lane * 16u;
   const float* wl1 = &Ws[4 * c4];
   const float* wl2 = &Ws[10 * C + 4 * c4];
   const f32x4 pbias1 = *(const f32x4*)&Bp[4 * c4];         // block 1's 1x1 bias rides its shortcut
@@ -221,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void blazepair_s2_kernel(BlazePairS2Args p)
           const float* arow = &At[lr * LDT + 4 * h];
           const float* s00 = ring + ((y - 1) & 3) * RROW + rg_ep2;            // y1 row 2 yo, pixel 2 X
           const float* s10 = ring + (y & 3) * RROW + rg_ep2;                  // y1 row 2 yo + 1
+          char* orow_g = outb + fp_uniform((long)yo * out_rb);
 #pragma unroll
           for (int nb = 0; nb < NB2; ++nb) {
             f32x16 m0, m1;
@@ -257,13 +257,9 @@ __global__ __launch_bounds__(256, 2) void blazepair_s2_kernel(BlazePairS2Args p)
               for (int e = 0; e < 4; ++e) v[e] = (m0[4 * j + e] + m1[4 * j + e]) + sv[e];
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-              *(f32x4*)&Ot[lr * C2 + oc + 4 * h] = v;
+              // straight to global memory: a lane pair (h = 0, 1) writes 32 contiguous bytes of its pixel (as blazepair.hip)
+              if (live) *(f32x4*)(orow_g + (unsigned)((lr * C2 + oc + 4 * h) * 4)) = v;
             }
-          }
-          if (live) {
-            char* orow_g = outb + fp_uniform((long)yo * out_rb);
-#pragma unroll
-            for (int j = 0; j < C2 / 8; ++j) *(f32x4*)(orow_g + voff_out + j * 1024) = *(const f32x4*)&Ot[(lane + 64 * j) * 4];
           }
         }
       }
