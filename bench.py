@@ -120,6 +120,9 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus
 # queue once the process group exists, and the two networks serialise (4.69 ms per step against 4.15 in the one-GPU RCCL
 # rehearsal).  Per-process runtime knob, read when HIP initialises; only set where the process group exists (with two streams
 # the default mapping is fine: 4.05 ms).
+# how this process came to be (before init_dist fills in defaults): started by launch_ranks, by an external launcher, or alone
+LAUNCH_MODE = ("self-launched (bench.py started the ranks)" if os.environ.get("BENCH_LAUNCHED_BY") == "bench.py" else
+               "external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "in-process, one rank")
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BENCH_FORCE_DIST"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -252,9 +255,7 @@ def check_world(args, world):
 def launch_record(args, world, rank, dev, dist, backend, count):
     """What the result line says about the job's shape: the world size the process group itself reports, the collective
     library, every rank's device and every rank's share of the processed units (all gathered through the group)."""
-    rec = {"mode": "self-launched (bench.py started the ranks)" if os.environ.get("BENCH_LAUNCHED_BY") == "bench.py"
-           else ("external launcher (WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "in-process, one rank"),
-           "requested_gpus": args.gpus, "world_size": world, "backend": None, "units_per_rank": [count], "devices": None}
+    rec = {"mode": LAUNCH_MODE, "requested_gpus": args.gpus, "world_size": world, "backend": None, "units_per_rank": [count], "devices": None}
     if dist is None:
         return rec
     mine = {"rank": rank, "units": int(count), "device": str(dev)}

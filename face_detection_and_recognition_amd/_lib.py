@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfacepath.so")
 
 FP_OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -24,6 +24,7 @@ OPF_IN_ROWPAD, OPF_OUT_ROWPAD = 1, 2   # fp_op.flags: row-padded input / output 
 OPF_IN_C3 = 4                          # 4-float pixel whose fourth channel meets zero weights
 OPF_IN_DW = 16                         # DWBLOCK: a depthwise Conv_block in front of the block, computed in its prologue
 OPF_IN_UP2 = 32                        # CONV (split pointwise): leading input channels = a half-size map upsampled 2x (nearest)
+OPF_OUT_DW = 64                        # CONV (Mobile-FaceNet stem): a depthwise 3x3 Conv_block behind the conv, in the same kernel
 OPF_SPLIT3 = 8                         # GEMM weights packed as three bf16 planes (bf16x6 split-MFMA kernels)
 
 

@@ -99,7 +99,14 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_BLAZECHAIN && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
-  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW | FP_OPF_IN_UP2)) return FP_ERR_INVALID_ARG;
+  if (op.flags & ~(FP_OPF_IN_ROWPAD | FP_OPF_OUT_ROWPAD | FP_OPF_IN_C3 | FP_OPF_SPLIT3 | FP_OPF_IN_DW | FP_OPF_IN_UP2 | FP_OPF_OUT_DW))
+    return FP_ERR_INVALID_ARG;
+  if (op.flags & FP_OPF_OUT_DW) {
+    // Mobile-FaceNet's conv1 + conv2_dw (facepath.h): the conv's slopes are followed by the depthwise block's [12][Cout]
+    if (op.kind != FP_OP_CONV) return FP_ERR_INVALID_ARG;
+    if (!fp_stemdw_supported(op)) return FP_ERR_UNSUPPORTED;
+    if (!span_ok(op.slope_off, 13 * (int64_t)op.Cout, weight_floats)) return FP_ERR_BOUNDS;
+  }
   if (op.flags & FP_OPF_IN_UP2) {
     // channels [0, res_C) come from the res view at half resolution (facepath.h): only the split-MFMA pointwise kernel reads that
     if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_SPLIT3)) return FP_ERR_INVALID_ARG;
@@ -279,6 +286,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
   if (!op) return "?";
   switch (op->kind) {
     case FP_OP_CONV: {
+      if (op->flags & FP_OPF_OUT_DW) return "stemdw_kernel";
       if (op->flags & FP_OPF_SPLIT3) {
         if (fp_pwx6_eligible(*op))
           snprintf(buf, sizeof(buf), "pwx6_kernel<%d, %d, %s>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8, fp_pwx6_mt(*op),

@@ -723,6 +723,7 @@ void fp_conv_variant(const fp_op& op, int* nb, int* vec, int* pwd) {
 }
 
 int fp_launch_conv(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
+  if (op.flags & FP_OPF_OUT_DW) return fp_launch_stemdw(op, weights, arena, s);
   if (op.flags & FP_OPF_SPLIT3)
     return fp_pwx6_eligible(op) ? fp_launch_pwx6(op, weights, arena, s) : fp_launch_convx6(op, weights, arena, s);
   if (fp_pws_eligible(op)) return fp_launch_pws(op, weights, arena, s);

@@ -41,6 +41,13 @@ namespace {
 #ifndef FP_X6_XCD
 #define FP_X6_XCD 1
 #endif
+// Lab knob: wave priority during the depthwise (VALU) phase.  The partner workgroup's MFMA stream takes the SIMD's issue port
+// for half of every MFMA; a D-phase wave with a higher priority gets the port whenever it is ready.
+#ifndef FP_X6_DPRIO
+#define FP_X6_DPRIO 0
+#endif
+#define X6_DPRIO_ON()  do { if (FP_X6_DPRIO) __builtin_amdgcn_s_setprio(FP_X6_DPRIO); } while (0)
+#define X6_DPRIO_OFF() do { if (FP_X6_DPRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 __device__ __forceinline__ int x6_tile_of_block() { return FP_X6_XCD ? (int)fp_xcd_block() : (int)blockIdx.x; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -327,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
     X6_STAMP(2);
     load_pbw(s);                           // first: vmcnt is in order, P waits for these and not for the DMA behind them
     if (s + 1 < R) stage(s + 1);
+    X6_DPRIO_ON();
     depthwise(s, std::integral_constant<int, 0>());
+    X6_DPRIO_OFF();
     X6_STAMP(3);
     lds_barrier();                         // D-tile complete
     X6_STAMP(4);
@@ -335,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
     X6_STAMP(5);
     if (K::NCHUNK > 1) {
       lds_barrier();                       // chunk 0's D-tile consumed
+      X6_DPRIO_ON();
       depthwise(s, std::integral_constant<int, K::NCHUNK - 1>());
+      X6_DPRIO_OFF();
       lds_barrier();
       project(std::integral_constant<int, K::NCHUNK - 1>());
     }
@@ -597,7 +608,9 @@ __global__ __launch_bounds__(256, 3) void dwblock_x6q_kernel(DwbX6Args p) {
     X6_STAMP(2);
     load_pbw(s);
     if (s + 1 < R) stage(s + 1);
+    X6_DPRIO_ON();
     depthwise(s);
+    X6_DPRIO_OFF();
     X6_STAMP(3);
     lds_barrier();
     X6_STAMP(4);
@@ -1250,7 +1263,9 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
     __syncthreads();
     load_pbw(s);
     if (s + 1 < R) stage(s + 1);
+    X6_DPRIO_ON();
     depthwise(s);
+    X6_DPRIO_OFF();
     lds_barrier();
     project();
     if (s + 1 < R) __syncthreads();

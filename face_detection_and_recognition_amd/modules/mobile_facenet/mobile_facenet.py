@@ -197,6 +197,7 @@ class MobileFaceNet(nn.Module):
     # conv2_dw + conv_23: True = depthwise launch + whole-block split-MFMA kernel; False = the round-2 pair of dw->pw kernels
     X6_CONV23 = True
     X6_CONV2_IN = True    # ... with conv2_dw inside that kernel's prologue (False: a separate depthwise launch)
+    STEM_DW = True        # conv1 + conv2_dw as ONE kernel (FP_OPF_OUT_DW, csrc/stemdw.hip); conv_23 then takes conv2_dw's output
 
     def __init__(self, embedding_size):
         super().__init__()
@@ -235,9 +236,26 @@ class MobileFaceNet(nn.Module):
         pb = PlanBuilder(N)
         pb.dwblock_shapes = block_shapes
         inp = pb.new_buf(H, W, 3)
-        x = self.conv1.emit(pb, inp.view())
-        c2, c23 = self.conv2_dw, self.conv_23
-        if (Depth_Wise.FUSE and Depth_Wise.X6 and MobileFaceNet.X6_CONV23 and c23.conv_dw.s == 2 and not c23.residual and
+        c1, c2, c23 = self.conv1, self.conv2_dw, self.conv_23
+        stem_dw = False
+        if (Depth_Wise.FUSE and MobileFaceNet.STEM_DW and c1.groups == 1 and (c1.k, c1.s, c1.p) == (3, 2, 1) and
+                (c2.k, c2.s, c2.p) == (3, 1, 1) and c2.groups == c2.in_c == c2.out_c == c1.out_c):
+            y = pb.new_buf(H // 2, W // 2, c1.out_c)
+            if pb.stem_dw_ok(inp.view(), npy(c1.conv.weight), y.view(), 2, (1, 1), L.ACT_PRELU, L.RES_NONE):
+                # conv1 + conv2_dw in ONE kernel (FP_OPF_OUT_DW, csrc/stemdw.hip): conv1's 56 x 56 x 64 rows stay in LDS, the
+                # depthwise conv runs on them there; conv_23 below then runs in its plain form (no FP_OPF_IN_DW prologue)
+                s1, b1 = _affine(c1.bn)
+                pb.conv(inp.view(), npy(c1.conv.weight), y.view(), stride=2, pad=(1, 1), scale=s1, bias=b1,
+                        slope=npy(c1.prelu.weight), act=L.ACT_PRELU,
+                        out_dw=(npy(c2.conv.weight), _affine(c2.bn), npy(c2.prelu.weight)))
+                x, stem_dw = y, True
+            else:
+                pb.free(y)
+        if not stem_dw:
+            x = c1.emit(pb, inp.view())
+        if stem_dw:
+            y = c23.emit(pb, x.view()); pb.free(x); x = y
+        elif (Depth_Wise.FUSE and Depth_Wise.X6 and MobileFaceNet.X6_CONV23 and c23.conv_dw.s == 2 and not c23.residual and
                 x.H == x.W and c2.out_c == c23.conv.in_c and
                 (c23.conv.in_c, c23.conv.out_c, c23.project.out_c, x.H) in pb.DWBLOCK_X6D_SHAPES):
             # conv2_dw + ALL of conv_23 (expand -> dw stride 2 -> project) as one split-MFMA kernel: conv2_dw is formed in

@@ -353,9 +353,19 @@ class PlanBuilder:
             u, x.up = x.up, None
             self.upsample2x(u, View(x.buf, x.coff, u.C))
 
+    @staticmethod
+    def stem_dw_ok(x, w, out, stride, pad, act, res_mode):
+        """Mirror of fp_stemdw_supported (csrc/stemdw.hip): Mobile-FaceNet's conv1 on a dense 112 x 112 4-float-pixel image."""
+        return (tuple(w.shape) == (64, 3, 3, 3) and stride == 2 and tuple(pad) == (1, 1) and act == L.ACT_PRELU and
+                res_mode == L.RES_NONE and (x.H, x.W, x.C) == (112, 112, 4) and x.buf.ld == 4 and x.coff == 0 and
+                x.up is None and not x.buf.rowpad and (out.H, out.W, out.C) == (56, 56, 64) and out.cmul == 1 and
+                out.coff == 0 and out.buf.ld == 64 and not out.buf.rowpad)
+
     def conv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None,
-             act=L.ACT_NONE, res=None, res_mode=L.RES_NONE, n_convs=1):
-        """Dense conv (OIHW weight); out is a View whose C >= Cout (extra channels get zeros)."""
+             act=L.ACT_NONE, res=None, res_mode=L.RES_NONE, n_convs=1, out_dw=None):
+        """Dense conv (OIHW weight); out is a View whose C >= Cout (extra channels get zeros).
+        out_dw = (weights [C,1,3,3], (scale, bias), PReLU slope) of a depthwise 3x3 stride-1 pad-1 Conv_block computed behind
+        the conv in the same kernel (FP_OPF_OUT_DW: Mobile-FaceNet's conv1 + conv2_dw); `out` then receives ITS output."""
         cout, cin, kh, kw = w.shape
         assert cin <= x.C, (cin, x.C)
         OH, OW = out.H, out.W
@@ -398,7 +408,16 @@ class PlanBuilder:
             op.scale_off = self.add_weight(pad_vec(scale, out.C, 0.0))
         if bias is not None:
             op.bias_off = self.add_weight(pad_vec(bias, out.C, 0.0))
-        if slope is not None:
+        if out_dw is not None:
+            # the conv's slopes followed by the depthwise block [12][Cout]: nine taps, BN scale, BN bias, PReLU slope
+            assert self.stem_dw_ok(x, w, out, stride, pad, act, res_mode) and slope is not None and not (op.flags & L.OPF_SPLIT3)
+            dw_w, dw_aff, dw_slope = out_dw
+            assert tuple(dw_w.shape) == (out.C, 1, 3, 3)
+            op.flags |= L.OPF_OUT_DW
+            op.slope_off = self.add_weight(np.concatenate([pad_vec(slope, out.C, 0.0), pack_dw_weight(dw_w, out.C),
+                                                           pad_vec(dw_aff[0], out.C), pad_vec(dw_aff[1], out.C),
+                                                           pad_vec(dw_slope, out.C)]))
+        elif slope is not None:
             op.slope_off = self.add_weight(pad_vec(slope, out.C, 0.0))
         if res_mode == L.RES_SHUFFLE2:   # out is the dense view of the conv's own Cout channels; 2*Cout are written
             assert out.cmul == 1 and out.coff + 2 * out.C <= out.buf.ld and res is not None and res.C >= out.C
@@ -412,7 +431,8 @@ class PlanBuilder:
         self.ops.append(op)
         # n_convs > 1: several reference convs on the same input merged into one op (their outputs concatenated): the
         # op-granular model counts the input once per conv
-        self.alg_bytes.append(4 * self.N * (n_convs * x.H * x.W * cin + OH * OW * cout))
+        # (FP_OPF_OUT_DW: + the depthwise conv's input and output, SURVEY 8d counts every conv)
+        self.alg_bytes.append(4 * self.N * (n_convs * x.H * x.W * cin + OH * OW * cout + (2 * OH * OW * cout if out_dw is not None else 0)))
         return out
 
     def dwconv(self, x, w, out, stride=1, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
@@ -1024,7 +1044,7 @@ class CompiledPlan:
         n = self.n_run if n is None else n
         k, opix = op.kind, op.OH * op.OW
         if k in (L.OP_CONV, L.OP_STEM_U8):
-            f = opix * op.KH * op.KW * op.Cin * op.Cout
+            f = opix * op.KH * op.KW * op.Cin * op.Cout + (opix * 9 * op.Cout if op.flags & L.OPF_OUT_DW else 0)
         elif k == L.OP_DWCONV:
             f = opix * op.KH * op.KW * op.Cin
         elif k in (L.OP_BLAZEBLOCK, L.OP_DWPW):

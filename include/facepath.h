@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 8
+#define FP_ABI_VERSION 9
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -189,6 +189,16 @@ typedef struct fp_op {
  *                read).  The upsampled tensor does not exist.
  */
 #define FP_OPF_IN_UP2 32
+/*
+ * FP_OPF_OUT_DW (ABI 9) : an FP_OP_CONV followed by a depthwise 3x3 stride-1 pad-1 Conv_block (conv + BN + PReLU,
+ *                mobile_facenet.py:39-51) computed in the same kernel -- Mobile-FaceNet's conv1 + conv2_dw (:107-108, :141-142):
+ *                the conv's output tile stays in LDS, the depthwise conv runs on it there and the op writes the DEPTHWISE
+ *                output (same shape: OH x OW x Cout).  slope_off -> [Cout] PReLU slopes of the conv followed by [12][Cout] of
+ *                the depthwise block: its nine taps (ky*3 + kx), BN scale, BN bias, PReLU slope.  Only the stem shape:
+ *                3x3 stride 2 pad 1 on a dense 112 x 112 four-float-pixel image (FP_OPF_IN_C3), Cout 64, scale / bias / PReLU
+ *                (csrc/stemdw.hip).
+ */
+#define FP_OPF_OUT_DW 64
 
 /*
  * Weight blob layouts (packed by the host side, see
@@ -250,7 +260,7 @@ typedef struct fp_op {
  *            [1280 floats: [9][96] depthwise taps (ky*3 + kx), [96] depthwise bias, [96] 1x1 bias, 224 pad] followed by
  *            three slabs (k = 32 s .. 32 s + 31) of [3 planes][96 output channels][32 k] bf16 (13 824 floats).
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

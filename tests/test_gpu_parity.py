@@ -1185,7 +1185,16 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
     plan = net.plan_for(64)
     ops = [plan.ops[i] for i in range(plan.n_ops)]
     assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 15   # + conv_23, conv_34, conv_45
+    assert plan.kernel_name(0) == "stemdw_kernel" and not any(o.flags & L.OPF_IN_DW for o in ops)   # conv1 + conv2_dw: one kernel
     e_x6 = run(plan)
+    MobileFaceNet.STEM_DW = False          # round 3's form: conv2_dw in the prologue of conv_23's kernel (FP_OPF_IN_DW)
+    try:
+        plan = net.plan_for(64)
+        assert any(plan.ops[i].flags & L.OPF_IN_DW for i in range(plan.n_ops)) and plan.kernel_name(0) != "stemdw_kernel"
+        e_indw = run(plan)
+    finally:
+        MobileFaceNet.STEM_DW = True
+    assert np.abs(e_indw - g["emb"]).max() < 1e-4 and np.abs(e_indw - e_x6).max() < 2e-6
     Depth_Wise.X6 = False
     try:
         Depth_Wise.BLOCK_SHAPES = (28, 14, 7)
@@ -1203,6 +1212,63 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
     for e in (e_x6, e_blk, e_two):
         assert np.abs(e - g["emb"]).max() < 1e-4
     assert np.abs(e_blk - e_two).max() < 2e-6 and np.abs(e_x6 - e_two).max() < 2e-6
+
+
+@pytest.mark.parametrize("n", [1, 3, 70, 530])
+def test_stemdw_conv1_plus_conv2_dw_in_one_kernel_vs_oracle(dev, n):
+    """FP_OPF_OUT_DW (csrc/stemdw.hip): Mobile-FaceNet's conv1 (3x3 stride 2 + BN + PReLU, mobile_facenet.py:107,141) and
+    conv2_dw (depthwise 3x3 + BN + PReLU, :108,142) in ONE kernel -- conv1's rows never leave LDS -- against the oracle's two
+    Conv_blocks in sequence (1e-5 of the output scale, element by element 2e-5 + 1e-5 relative), against the two separate
+    launches (stem kernel, then depthwise kernel: conv1 is bit-identical arithmetic, so 2e-6), every output written, the
+    image borders (zero padding of BOTH convs) and first / interior / last bands; batches below and above one round of
+    workgroups."""
+    from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Conv_block, _affine
+    from face_detection_and_recognition_amd.modules.params import npy
+    rng = np.random.default_rng(900 + n)
+    c1 = Conv_block(3, 64, kernel=(3, 3), stride=(2, 2), padding=(1, 1))
+    c2 = Conv_block(64, 64, kernel=(3, 3), stride=(1, 1), padding=(1, 1), groups=64)
+    sd1, sd2 = synth_state_dict(c1.state_dict(), 1500), synth_state_dict(c2.state_dict(), 1501)
+    c1.load_state_dict(sd1)
+    c2.load_state_dict(sd2)
+    x = rng.uniform(-1, 1, (n, 3, 112, 112)).astype(np.float32)
+    x[0, :, :3, :] = 1.0                      # a bright top edge / corner: the zero padding must show in the borders
+    x[-1, :, -2:, -2:] = -1.0
+
+    def run(fused):
+        pb = PlanBuilder(n)
+        inp = pb.new_buf(112, 112, 3)
+        if fused:
+            y = pb.new_buf(56, 56, 64)
+            s1, b1 = _affine(c1.bn)
+            pb.conv(inp.view(), npy(c1.conv.weight), y.view(), stride=2, pad=(1, 1), scale=s1, bias=b1, slope=npy(c1.prelu.weight),
+                    act=L.ACT_PRELU, out_dw=(npy(c2.conv.weight), _affine(c2.bn), npy(c2.prelu.weight)))
+        else:
+            y = c2.emit(pb, c1.emit(pb, inp.view()).view())
+        plan = CompiledPlan(pb, dev)
+        t = plan.buf_tensor(inp, n)
+        t[..., :3].copy_(torch.from_numpy(x).to(dev).permute(0, 2, 3, 1))
+        t[..., 3:].zero_()
+        out_t = plan.buf_tensor(y, n)
+        out_t.fill_(float("nan"))
+        plan.run()
+        torch.cuda.synchronize()
+        return plan, out_t.permute(0, 3, 1, 2).cpu().numpy()
+    plan, got = run(True)
+    assert plan.n_ops == 1 and plan.kernel_name(0) == "stemdw_kernel" and plan.ops[0].flags & L.OPF_OUT_DW
+    plan2, two = run(False)
+    assert plan2.n_ops == 2
+    xt = torch.from_numpy(x)
+    sd = {"conv1." + k: torch.as_tensor(v) for k, v in sd1.items()}
+    sd.update({"conv2_dw." + k: torch.as_tensor(v) for k, v in sd2.items()})
+    ref = mobilefacenet_ref._conv_block(sd, "conv2_dw.", mobilefacenet_ref._conv_block(sd, "conv1.", xt, 2, 1, 1), 1, 1, 64).numpy()
+    assert got.shape == ref.shape == (n, 64, 56, 56) and np.isfinite(got).all()
+    assert rel_err(got, ref) < 1e-5
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got, two, rtol=0, atol=2e-6 * np.abs(ref).max())
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref64 = mobilefacenet_ref._conv_block(sd64, "conv2_dw.", mobilefacenet_ref._conv_block(sd64, "conv1.", xt.double(), 2, 1, 1),
+                                          1, 1, 64).numpy()
+    assert np.abs(got - ref64).max() <= 2.0 * np.abs(ref - ref64).max()       # plain fp32 arithmetic: no worse than the oracle's
 
 
 @pytest.mark.parametrize("ks,cout,hw,n,act", [(5, 24, 256, 8, "relu"), (3, 64, 112, 48, "prelu"), (3, 24, 90, 70, "none")])
