@@ -106,6 +106,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.kind != FP_OP_CONV) return FP_ERR_INVALID_ARG;
     if (!fp_stemdw_supported(op)) return FP_ERR_UNSUPPORTED;
     if (!span_ok(op.slope_off, 13 * (int64_t)op.Cout, weight_floats)) return FP_ERR_BOUNDS;
+    if (!span_ok(op.w_off, fp_stemdw_w_floats(op), weight_floats)) return FP_ERR_BOUNDS;
   }
   if (op.flags & FP_OPF_IN_UP2) {
     // channels [0, res_C) come from the res view at half resolution (facepath.h): only the split-MFMA pointwise kernel reads that
@@ -118,7 +119,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW && op.kind != FP_OP_BLAZECHAIN)
     return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_DWPW && !fp_dwpwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
-  if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op)) return FP_ERR_UNSUPPORTED;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !(op.flags & FP_OPF_OUT_DW) && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op))
+    return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_IN_C3) && (op.Cin != 4 || (op.kind != FP_OP_CONV && op.kind != FP_OP_YSTEM)))
     return FP_ERR_INVALID_ARG;
   const bool in_rp = (op.flags & FP_OPF_IN_ROWPAD) != 0, out_rp = (op.flags & FP_OPF_OUT_ROWPAD) != 0;
@@ -170,6 +172,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
       const int64_t K = (int64_t)op.KH * op.KW * (op.kind == FP_OP_STEM_U8 ? 4 : op.Cin);
       wext = ((K + 7) / 8 * 8) * ((op.Cout + 31) / 32 * 32);
       if (op.flags & FP_OPF_SPLIT3) wext = fp_convx6_w_floats(op);   // three bf16 planes: 1.5 floats per (padded) weight
+      if (op.flags & FP_OPF_OUT_DW) wext = fp_stemdw_w_floats(op);
     } else {
       // BLAZEBLOCK: dw weights [9][Cin] followed (separately addressed) by the packed 1x1; w_off addresses the
       // dw weights, scale_off the dw bias, slope_off the packed pointwise weights, bias_off the pointwise bias.
@@ -286,7 +289,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
   if (!op) return "?";
   switch (op->kind) {
     case FP_OP_CONV: {
-      if (op->flags & FP_OPF_OUT_DW) return "stemdw_kernel";
+      if (op->flags & FP_OPF_OUT_DW) return (op->flags & FP_OPF_SPLIT3) ? "stemdw_kernel<true>" : "stemdw_kernel<false>";
       if (op->flags & FP_OPF_SPLIT3) {
         if (fp_pwx6_eligible(*op))
           snprintf(buf, sizeof(buf), "pwx6_kernel<%d, %d, %s>", op->Cout == 48 ? 3 : op->Cout == 64 ? 4 : 8, fp_pwx6_mt(*op),

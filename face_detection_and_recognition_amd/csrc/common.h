@@ -131,6 +131,7 @@ int fp_launch_pws(const fp_op& op, const float* weights, float* arena, hipStream
 bool fp_stem_eligible(const fp_op& op);     // KxK stride-2 convs on a 4-float-pixel image (network stems)
 int fp_launch_stem(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stemdw_supported(const fp_op& op);   // CONV + FP_OPF_OUT_DW: Mobile-FaceNet's conv1 + conv2_dw in one kernel (stemdw.hip)
+long fp_stemdw_w_floats(const fp_op& op);
 int fp_launch_stemdw(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_stem_u8_shape_ok(const fp_op& op);
 bool fp_stem_u8_band_eligible(const fp_op& op);   // BlazeFace's 5x5 stem on u8 frames, band kernel (canvas rows in an LDS ring)

@@ -21,14 +21,14 @@
 //   dw       = lane = (4 channels, column), marching down the 4 rows with a 3-row window in registers; fma chain over the
 //              taps in dwblockx6.hip's order, BN as acc * s + b, PReLU as v + (slope - 1) * min(v, 0)
 //   output   = 16-byte stores, 128 contiguous bytes per pixel and pass
-#include "common.h"
+#include "split.h"
 
 namespace {
 
 struct StemDwArgs {
   const float* in;     // [N][112][112][4]
   float* out;          // [N][56][56][64]
-  const float* w;      // conv1 packed [Kpad/4][64][4] (pack_conv_weight: k-quad = tap)
+  const float* w;      // conv1 packed [Kpad/4][64][4] (pack_conv_weight: k-quad = tap); X6: three bf16 planes [4 nt][3][16 ch][32 k]
   const float* scale;  // [64] conv1 BN scale, bias, PReLU slope
   const float* bias;
   const float* slope;
@@ -47,6 +47,11 @@ constexpr int SD_LDS = 4 * (SD_IMG + SD_C1 + SD_PAR + SD_DWP);
 constexpr int SD_PF = (SD_IR * SD_IW + 255) / 256;    // staged float4s per thread and tile (6)
 static_assert(2 * SD_LDS <= 160 * 1024, "two workgroups per CU");
 
+// X6 = true (FP_OPF_SPLIT3): conv1 on the bf16 matrix cores with fp32-equivalent arithmetic (split.h): K = 27 = (tap, channel)
+// flattened into ONE 32-k slab (zero weights behind it), 16-pixel tiles, the pixel fragments gathered value by value from the
+// staged rows and split per tile and pass, weights as three bf16 planes in registers:
+// 12 MFMAs of 16 cycles per 16 pixels and pass on the matrix pipe instead of 15 of 64 on the vector ALU.
+template <bool X6>
 __global__ __launch_bounds__(256, 2) void stemdw_kernel(StemDwArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Img = smem;              // [13][114][4]
@@ -67,15 +72,33 @@ __global__ __launch_bounds__(256, 2) void stemdw_kernel(StemDwArgs p) {
   }
   // A operand of the swapped MFMA = conv1's weights: fragment (k-quad = tap 2 kq + h, row = channel 32 pass + lr); the tenth
   // tap does not exist: zeros.  Packed blob: [k-quad = tap][64][4]
-  f32x4 wf[2][5];
+  f32x4 wf[X6 ? 1 : 2][X6 ? 1 : 5];
+  fp_frag3 w3[X6 ? 4 : 1];            // X6: channel tile nt = 16 nt + l15, k = 8 q .. + 7
+  const int l15 = lane & 15, q = lane >> 4;
+  int koff[8];                        // X6: float offset of k = 8 q + i = (tap, channel) inside a pixel's 3 x 3 window
+  if (X6) {
+    const unsigned short* wp = (const unsigned short*)p.w;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-    for (int kq = 0; kq < 5; ++kq) {
-      const int t = 2 * kq + h;
-      const f32x4 v = *(const f32x4*)(p.w + ((long)(t < 9 ? t : 0) * SD_C + pass * 32 + lr) * 4);
-      wf[pass][kq] = t < 9 ? v : z4;
+    for (int nt = 0; nt < 4; ++nt) {
+      w3[nt].h = *(const u32x4*)(wp + ((nt * 3 + 0) * 16 + l15) * 32 + 8 * q);
+      w3[nt].m = *(const u32x4*)(wp + ((nt * 3 + 1) * 16 + l15) * 32 + 8 * q);
+      w3[nt].l = *(const u32x4*)(wp + ((nt * 3 + 2) * 16 + l15) * 32 + 8 * q);
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 8 * q + i, tap = k < 27 ? k / 3 : 0, c = k < 27 ? k - tap * 3 : 0;
+      koff[i] = ((tap / 3) * SD_IW + tap % 3) * 4 + c;
+    }
+  } else {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int kq = 0; kq < 5; ++kq) {
+        const int t = 2 * kq + h;
+        const f32x4 v = *(const f32x4*)(p.w + ((long)(t < 9 ? t : 0) * SD_C + pass * 32 + lr) * 4);
+        wf[pass][kq] = t < 9 ? v : z4;
+      }
+  }
 
   // staging of a tile's input rows 2 r0 - 3 .. 2 r0 + 9, columns -1 .. 112: thread -> float4 slots tid + 256 j
   int srow[SD_PF], scol[SD_PF];
@@ -124,45 +147,82 @@ __global__ __launch_bounds__(256, 2) void stemdw_kernel(StemDwArgs p) {
       // ---- conv1 for channels 32 pass .. + 31: 6 x 56 = 336 pixels = 10.5 tiles of 32, wave w owns tiles w, w + 4, w + 8 ----
       // swapped operands: A = weights (row = channel lr of the pass), B = pixels (column = pixel lr of the tile); lane (lr, h)
       // ends up with PIXEL lr and channels (reg & 3) + 8 (reg >> 2) + 4 h: 16-byte pieces of the pixel's channel row
-#pragma unroll 1
-      for (int mt = wave; mt * 32 < SD_CR * SD_OH; mt += 4) {
-        const int m = min(mt * 32 + lr, SD_CR * SD_OH - 1);
-        const int cy = m / SD_OH, cx = m - cy * SD_OH;             // conv1 pixel (row r0 - 1 + cy, column cx)
-        const float* base = Img + ((cy * 2) * SD_IW + cx * 2) * 4;   // its window: staged rows 2 cy .. + 2, columns 2 cx .. + 2
-        // two accumulators, strictly alternating: a 32x32x2 MFMA that accumulates into the previous MFMA's result issues at
-        // half rate (common.h FP_MFMA_ORDER); even MFMAs of the k sequence go to acc0, odd ones to acc1, summed at the end
-        f32x16 acc0, acc1;
+      if (X6) {
+        // 336 pixels = 21 tiles of 16; wave w owns tiles w, w + 4, ... (6 / 5 / 5 / 5); lane (l15, q) ends up with PIXEL l15 and
+        // channels 4 q .. + 3 of each 16-channel tile
+        constexpr int NT16 = SD_CR * SD_OH / 16, NOWN = (NT16 + 3) / 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+        for (int t = 0; t < NOWN; ++t) {
+          const int mt = wave + 4 * t;
+          if (mt < NT16) {                                           // wave-uniform
+            const int m = mt * 16 + l15;
+            const int cy = m / SD_OH, cx = m - cy * SD_OH;
+            const float* base = Img + ((cy * 2) * SD_IW + cx * 2) * 4;
+            f32x4 lo, hi;
 #pragma unroll
-        for (int kq = 0; kq < 5; ++kq) {
-          // fragment of 4 consecutive k = tap 2 kq + h (the tenth: zero weights, any staged pixel)
-          const int t = 2 * kq + h;
-          const int tt = t < 9 ? t : 0;
-          const int ky = tt / 3, kx = tt - ky * 3;
-          const f32x4 a = *(const f32x4*)(base + (ky * SD_IW + kx) * 4);
+            for (int i = 0; i < 4; ++i) lo[i] = base[koff[i]], hi[i] = base[koff[4 + i]];
+            const fp_frag3 pf = fp_split8(lo, hi);    // (gathered and split again in the second pass: 8 LDS reads + 36 VALU per tile
+                                                      // are cheaper than 72 registers held across the depthwise phase)
+            f32x4 acc0 = z4, acc1 = z4;
+            fp_mfma_x6_2a(w3[2 * pass], w3[2 * pass + 1], pf.h, pf.m, pf.l, acc0, acc1);
+            const bool inside = (unsigned)(r0 - 1 + cy) < (unsigned)SD_OH;
+            float* dst = C1 + (cy * SD_CW + cx + 1) * SD_LDC + 4 * q;
 #pragma unroll
-          for (int e = 0; e < 3; ++e) {
-            if ((3 * kq + e) & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[pass][kq][e], a[e], acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[pass][kq][e], a[e], acc0, 0, 0, 0);
-            FP_MFMA_ORDER();
+            for (int nt = 0; nt < 2; ++nt) {
+              const int ch = pass * 32 + 16 * nt + 4 * q;
+              const f32x4 sc = *(const f32x4*)&Par[ch], bi = *(const f32x4*)&Par[SD_C + ch], sl = *(const f32x4*)&Par[2 * SD_C + ch];
+              const f32x4 av = nt ? acc1 : acc0;
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x = av[e] * sc[e] + bi[e];
+                v[e] = x > 0.f ? x : __builtin_fmaf(x, sl[e], 0.0f);
+              }
+              *(f32x4*)(dst + 16 * nt) = inside ? v : z4;
+            }
           }
         }
-        if (mt * 32 + lr < SD_CR * SD_OH) {
-          // conv1 rows outside the image are the depthwise conv's zero padding
-          const bool inside = (unsigned)(r0 - 1 + cy) < (unsigned)SD_OH;
-          float* dst = C1 + (cy * SD_CW + cx + 1) * SD_LDC + 4 * h;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ch = pass * 32 + 8 * j + 4 * h;
-            const f32x4 sc = *(const f32x4*)&Par[ch], bi = *(const f32x4*)&Par[SD_C + ch], sl = *(const f32x4*)&Par[2 * SD_C + ch];
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = (acc0[4 * j + e] + acc1[4 * j + e]) * sc[e] + bi[e];
-              v[e] = x > 0.f ? x : __builtin_fmaf(x, sl[e], 0.0f);
+      } else {
+  #pragma unroll 1
+        for (int mt = wave; mt * 32 < SD_CR * SD_OH; mt += 4) {
+          const int m = min(mt * 32 + lr, SD_CR * SD_OH - 1);
+          const int cy = m / SD_OH, cx = m - cy * SD_OH;             // conv1 pixel (row r0 - 1 + cy, column cx)
+          const float* base = Img + ((cy * 2) * SD_IW + cx * 2) * 4;   // its window: staged rows 2 cy .. + 2, columns 2 cx .. + 2
+          // two accumulators, strictly alternating: a 32x32x2 MFMA that accumulates into the previous MFMA's result issues at
+          // half rate (common.h FP_MFMA_ORDER); even MFMAs of the k sequence go to acc0, odd ones to acc1, summed at the end
+          f32x16 acc0, acc1;
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+  #pragma unroll
+          for (int kq = 0; kq < 5; ++kq) {
+            // fragment of 4 consecutive k = tap 2 kq + h (the tenth: zero weights, any staged pixel)
+            const int t = 2 * kq + h;
+            const int tt = t < 9 ? t : 0;
+            const int ky = tt / 3, kx = tt - ky * 3;
+            const f32x4 a = *(const f32x4*)(base + (ky * SD_IW + kx) * 4);
+  #pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              if ((3 * kq + e) & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[pass][kq][e], a[e], acc1, 0, 0, 0);
+              else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[pass][kq][e], a[e], acc0, 0, 0, 0);
+              FP_MFMA_ORDER();
             }
-            *(f32x4*)(dst + 8 * j) = inside ? v : z4;
+          }
+          if (mt * 32 + lr < SD_CR * SD_OH) {
+            // conv1 rows outside the image are the depthwise conv's zero padding
+            const bool inside = (unsigned)(r0 - 1 + cy) < (unsigned)SD_OH;
+            float* dst = C1 + (cy * SD_CW + cx + 1) * SD_LDC + 4 * h;
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ch = pass * 32 + 8 * j + 4 * h;
+              const f32x4 sc = *(const f32x4*)&Par[ch], bi = *(const f32x4*)&Par[SD_C + ch], sl = *(const f32x4*)&Par[2 * SD_C + ch];
+              f32x4 v;
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x = (acc0[4 * j + e] + acc1[4 * j + e]) * sc[e] + bi[e];
+                v[e] = x > 0.f ? x : __builtin_fmaf(x, sl[e], 0.0f);
+              }
+              *(f32x4*)(dst + 8 * j) = inside ? v : z4;
+            }
           }
         }
       }
@@ -224,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void stemdw_kernel(StemDwArgs p) {
 // Mobile-FaceNet's conv1 with conv2_dw behind it: FP_OP_CONV + FP_OPF_OUT_DW on a dense 112 x 112 four-float-pixel image.
 bool fp_stemdw_supported(const fp_op& op) {
   if (op.kind != FP_OP_CONV || !(op.flags & FP_OPF_OUT_DW) || !(op.flags & FP_OPF_IN_C3)) return false;
-  if (op.flags & ~(FP_OPF_OUT_DW | FP_OPF_IN_C3)) return false;
+  if (op.flags & ~(FP_OPF_OUT_DW | FP_OPF_IN_C3 | FP_OPF_SPLIT3)) return false;
   if (op.H != SD_H || op.W != SD_H || op.OH != SD_OH || op.OW != SD_OH || op.Cin != 4 || op.Cout != SD_C) return false;
   if (op.KH != 3 || op.KW != 3 || op.stride != 2 || op.pad_t != 1 || op.pad_l != 1) return false;
   if (op.in_ld != 4 || op.out_ld != SD_C || op.out_cmul != 1) return false;
@@ -233,6 +293,9 @@ bool fp_stemdw_supported(const fp_op& op) {
   if (op.in_off % 4 || op.out_off % 4 || op.in_ns % 4 || op.out_ns % 4 || op.w_off % 4 || op.slope_off % 4) return false;
   return op.in_ns >= (long)SD_H * SD_H * 4 && op.out_ns >= (long)SD_OH * SD_OH * SD_C;
 }
+
+// floats behind w_off: the packed fp32 weights (40 x 64), or with FP_OPF_SPLIT3 three bf16 planes [4][3][16][32]
+long fp_stemdw_w_floats(const fp_op& op) { return (op.flags & FP_OPF_SPLIT3) ? 4 * 3 * 16 * 32 / 2 : 40 * 64; }
 
 int fp_launch_stemdw(const fp_op& op, const float* weights, float* arena, hipStream_t s) {
   if (!fp_stemdw_supported(op)) return FP_ERR_UNSUPPORTED;
@@ -247,13 +310,16 @@ int fp_launch_stemdw(const fp_op& op, const float* weights, float* arena, hipStr
   a.in_ns = op.in_ns;
   a.out_ns = op.out_ns;
   a.N = op.N;
-  const hipError_t ae = hipFuncSetAttribute((const void*)stemdw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS);
+  const bool x6 = (op.flags & FP_OPF_SPLIT3) != 0;
+  const hipError_t ae = hipFuncSetAttribute(x6 ? (const void*)stemdw_kernel<true> : (const void*)stemdw_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
     return FP_ERR_LAUNCH;
   }
-  const int ntiles = op.N * SD_NBAND;
-  hipLaunchKernelGGL(stemdw_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(256), SD_LDS, s, a);   // persistent: two workgroups per CU
+  const int ntiles = op.N * SD_NBAND, grid = ntiles < 512 ? ntiles : 512;      // persistent: two workgroups per CU
+  if (x6) hipLaunchKernelGGL(stemdw_kernel<true>, dim3(grid), dim3(256), SD_LDS, s, a);
+  else hipLaunchKernelGGL(stemdw_kernel<false>, dim3(grid), dim3(256), SD_LDS, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }

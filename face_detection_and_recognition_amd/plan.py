@@ -382,7 +382,15 @@ class PlanBuilder:
             op.flags |= L.OPF_IN_UP2
             op.res_ld, op.res_ns, op.res_off = u.buf.ld, u.buf.ns, u.buf.off + u.coff
             op.res_C, op.res_H, op.res_W = u.C, u.H, u.W
-        if self.pwx6_ok(x, out, kh, kw, stride, pad, res, res_mode) and not (op.flags & ~L.OPF_IN_UP2):
+        if out_dw is not None and self.X6:
+            # FP_OPF_OUT_DW + FP_OPF_SPLIT3 (csrc/stemdw.hip): K = (tap, channel) flattened into one 32-k slab, three bf16 planes
+            # [channel tile of 16][plane][channel][32 k]
+            flat = np.zeros((cout, 32), np.float32)
+            flat[:, :kh * kw * cin] = np.asarray(w, np.float32).transpose(0, 2, 3, 1).reshape(cout, -1)     # k = (ky*3 + kx)*3 + c
+            w3 = split3_bf16(flat).reshape(3, cout // 16, 16, 32).transpose(1, 0, 2, 3)
+            op.w_off = self.add_weight(np.ascontiguousarray(w3).reshape(-1).view(np.float32))
+            op.flags |= L.OPF_SPLIT3
+        elif self.pwx6_ok(x, out, kh, kw, stride, pad, res, res_mode) and not (op.flags & ~L.OPF_IN_UP2):
             # three bf16 planes [tap * CS + cs][3][Npad][32] (include/facepath.h, FP_OPF_SPLIT3 on FP_OP_CONV): K runs
             # over (tap, 32-channel slab), zero rows / columns in the padding of Cin to 32 and Cout to whole chunks
             cs = (x.C + 31) // 32
@@ -410,7 +418,7 @@ class PlanBuilder:
             op.bias_off = self.add_weight(pad_vec(bias, out.C, 0.0))
         if out_dw is not None:
             # the conv's slopes followed by the depthwise block [12][Cout]: nine taps, BN scale, BN bias, PReLU slope
-            assert self.stem_dw_ok(x, w, out, stride, pad, act, res_mode) and slope is not None and not (op.flags & L.OPF_SPLIT3)
+            assert self.stem_dw_ok(x, w, out, stride, pad, act, res_mode) and slope is not None
             dw_w, dw_aff, dw_slope = out_dw
             assert tuple(dw_w.shape) == (out.C, 1, 3, 3)
             op.flags |= L.OPF_OUT_DW

@@ -1185,12 +1185,12 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
     plan = net.plan_for(64)
     ops = [plan.ops[i] for i in range(plan.n_ops)]
     assert sum(1 for o in ops if o.kind == L.OP_DWBLOCK and o.flags & L.OPF_SPLIT3) == 15   # + conv_23, conv_34, conv_45
-    assert plan.kernel_name(0) == "stemdw_kernel" and not any(o.flags & L.OPF_IN_DW for o in ops)   # conv1 + conv2_dw: one kernel
+    assert plan.kernel_name(0) == "stemdw_kernel<true>" and not any(o.flags & L.OPF_IN_DW for o in ops)   # conv1 + conv2_dw: one kernel
     e_x6 = run(plan)
     MobileFaceNet.STEM_DW = False          # round 3's form: conv2_dw in the prologue of conv_23's kernel (FP_OPF_IN_DW)
     try:
         plan = net.plan_for(64)
-        assert any(plan.ops[i].flags & L.OPF_IN_DW for i in range(plan.n_ops)) and plan.kernel_name(0) != "stemdw_kernel"
+        assert any(plan.ops[i].flags & L.OPF_IN_DW for i in range(plan.n_ops)) and not plan.kernel_name(0).startswith("stemdw_kernel")
         e_indw = run(plan)
     finally:
         MobileFaceNet.STEM_DW = True
@@ -1214,14 +1214,15 @@ def test_mobilefacenet_forward_with_whole_block_kernels_vs_reference_golden(dev)
     assert np.abs(e_blk - e_two).max() < 2e-6 and np.abs(e_x6 - e_two).max() < 2e-6
 
 
+@pytest.mark.parametrize("x6", [True, False])
 @pytest.mark.parametrize("n", [1, 3, 70, 530])
-def test_stemdw_conv1_plus_conv2_dw_in_one_kernel_vs_oracle(dev, n):
+def test_stemdw_conv1_plus_conv2_dw_in_one_kernel_vs_oracle(dev, n, x6):
     """FP_OPF_OUT_DW (csrc/stemdw.hip): Mobile-FaceNet's conv1 (3x3 stride 2 + BN + PReLU, mobile_facenet.py:107,141) and
     conv2_dw (depthwise 3x3 + BN + PReLU, :108,142) in ONE kernel -- conv1's rows never leave LDS -- against the oracle's two
     Conv_blocks in sequence (1e-5 of the output scale, element by element 2e-5 + 1e-5 relative), against the two separate
-    launches (stem kernel, then depthwise kernel: conv1 is bit-identical arithmetic, so 2e-6), every output written, the
-    image borders (zero padding of BOTH convs) and first / interior / last bands; batches below and above one round of
-    workgroups."""
+    launches (stem kernel, then depthwise kernel: 2e-6), every output written, the image borders (zero padding of BOTH convs)
+    and first / interior / last bands; batches below and above one round of workgroups.  x6: conv1 on the bf16 matrix cores
+    with the exact three-way operand split (stemdw_kernel<true>, the default) / on the fp32 MFMA (PlanBuilder.X6 off)."""
     from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Conv_block, _affine
     from face_detection_and_recognition_amd.modules.params import npy
     rng = np.random.default_rng(900 + n)
@@ -1253,8 +1254,13 @@ def test_stemdw_conv1_plus_conv2_dw_in_one_kernel_vs_oracle(dev, n):
         plan.run()
         torch.cuda.synchronize()
         return plan, out_t.permute(0, 3, 1, 2).cpu().numpy()
-    plan, got = run(True)
-    assert plan.n_ops == 1 and plan.kernel_name(0) == "stemdw_kernel" and plan.ops[0].flags & L.OPF_OUT_DW
+    x6_was, PlanBuilder.X6 = PlanBuilder.X6, x6
+    try:
+        plan, got = run(True)
+    finally:
+        PlanBuilder.X6 = x6_was
+    assert plan.n_ops == 1 and plan.kernel_name(0) == ("stemdw_kernel<true>" if x6 else "stemdw_kernel<false>")
+    assert plan.ops[0].flags & L.OPF_OUT_DW and bool(plan.ops[0].flags & L.OPF_SPLIT3) == x6
     plan2, two = run(False)
     assert plan2.n_ops == 2
     xt = torch.from_numpy(x)

@@ -57,6 +57,35 @@ def test_plans_validate_and_reject_bad_offsets(lib):
     assert lib.fp_plan_validate(None, 0, 0, 0) == -1
 
 
+def test_stem_with_depthwise_op_validation(lib):
+    """FP_OPF_OUT_DW (Mobile-FaceNet's conv1 + conv2_dw in one kernel, csrc/stemdw.hip): the first op of the embedder plan in both
+    arithmetic forms; the validator checks the depthwise block behind the conv's slopes and the split weight planes, and refuses
+    the flag on any other shape or op kind."""
+    from face_detection_and_recognition_amd.modules.mobile_facenet.mobile_facenet import Depth_Wise
+    for x6 in (True, False):
+        Depth_Wise.X6 = x6
+        try:
+            pb = MobileFaceNet(512)._emit(3)[0]
+        finally:
+            Depth_Wise.X6 = True
+        ops, weights, arena = pb.finish()
+        op = ops[0]
+        assert op.kind == L.OP_CONV and op.flags & L.OPF_OUT_DW and op.flags & L.OPF_IN_C3 and bool(op.flags & L.OPF_SPLIT3) == x6
+        assert lib.fp_op_kernel_name(ctypes.byref(op)).decode() == ("stemdw_kernel<true>" if x6 else "stemdw_kernel<false>")
+        assert (op.H, op.W, op.OH, op.OW, op.Cin, op.Cout, op.stride) == (112, 112, 56, 56, 4, 64, 2)
+        arr = (L.FpOp * len(ops))(*ops)
+        assert lib.fp_plan_validate(arr, len(ops), weights.size, arena) == 0
+        bad = (L.FpOp * len(ops))(*ops)
+        bad[0].slope_off = weights.size - 13 * 64 + 4                 # the depthwise block would end behind the blob
+        assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -2
+        bad = (L.FpOp * len(ops))(*ops)
+        bad[0].act = L.ACT_RELU                                       # the kernel exists for BN + PReLU only
+        assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == -3
+        bad = (L.FpOp * len(ops))(*ops)
+        bad[1].flags |= L.OPF_OUT_DW                                  # not a CONV (invalid) / a CONV of another shape (unsupported)
+        assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == (-1 if ops[1].kind != L.OP_CONV else -3)
+
+
 def test_blazeface_plans_validate_at_any_batch(lib):
     """The band rules of the pair kernels depend on the batch (fp_blazepair_band_rows: fewer, longer bands when there are many
     images): every batch size must still give a plan the validator accepts (a 64-row band on the 64 x 64 map -- one band per
@@ -402,7 +431,7 @@ def test_split3_plan_layouts_and_validation():
         finally:
             Depth_Wise.X6 = True
     assert all(v == 0 for k, v in counts.items() if not k[2])
-    assert counts[("MobileFaceNet", "", True)] == 17          # 15 Depth_Wise blocks + conv_6_sep + the Linear
+    assert counts[("MobileFaceNet", "", True)] == 18          # conv1 (stemdw_kernel<true>) + 15 Depth_Wise blocks + conv_6_sep + the Linear
     assert all(v > 0 for k, v in counts.items() if k[2])
 
 
