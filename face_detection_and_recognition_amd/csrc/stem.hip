@@ -361,6 +361,9 @@ int fp_launch_stem_u8(const fp_op& op, const float* weights, float* arena, const
 //     float4s, three ds_write_b128 into the wave's private output tile, three coalesced 16-byte global stores;
 //   * same k order (tap pairs 2kq + h, three channels per tap) and the same resampling code as the generic kernel and
 //     the stand-alone letterbox: bit-identical results.
+#ifndef FP_STEM_ACC2
+#define FP_STEM_ACC2 0
+#endif
 namespace {
 
 struct StemBandArgs {
@@ -453,9 +456,9 @@ __global__ __launch_bounds__(256, 3) void stem5_u8_band_kernel(StemBandArgs p) {
     int rb[5];                                           // float offsets of ring rows r0 .. r0 + 4 (wave-uniform)
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) rb[ky] = ((r0 + ky) & 7) * (SB_WP * 4);
-    f32x16 acc;
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f, acc1[i] = 0.f;
 #pragma unroll
     for (int kq = 0; kq < SB_KQ; ++kq) {
       // tap 2kq + h (a tap past the 25th meets zero weights: any finite pixel will do -> tap 0)
@@ -463,8 +466,22 @@ __global__ __launch_bounds__(256, 3) void stem5_u8_band_kernel(StemBandArgs p) {
       const int o0 = rb[t0 / 5] + (t0 % 5) * 4, o1 = rb[t1 / 5] + (t1 % 5) * 4;
       const f32x4 a = *(const f32x4*)&Ring[(h ? o1 : o0) + px_off];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[kq][e], a[e], acc, 0, 0, 0);
+      for (int e = 0; e < 3; ++e) {
+#if FP_STEM_ACC2
+        // two accumulators, strictly alternating (a 32x32x2 MFMA that accumulates into the previous one's result issues at
+        // half rate, common.h): MFMA i of the k sequence goes to accumulator i & 1, the two are summed once at the end
+        if ((3 * kq + e) & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[kq][e], a[e], acc1, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[kq][e], a[e], acc, 0, 0, 0);
+        FP_MFMA_ORDER();
+#else
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[kq][e], a[e], acc, 0, 0, 0);
+#endif
+      }
     }
+#if FP_STEM_ACC2
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+#endif
     if (more) finish_rows(r0 + 5);                       // other rows than the ones any wave is reading in this step
     // bias + ReLU on this lane's pixel, channels 8j + 4h .. + 3 -> the wave's tile -> 3 x 16-byte coalesced stores
 #pragma unroll
