@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void blazeblock_kernel(BlazeArgs p) {
 //
 // Nothing in this kernel is saturated (rocprofv3 SQ counters: VALU ~36 % of a SIMD, MFMA pipe 21 %, HBM 3.5-3.9
 // TB/s): it is bound by the serial chain of one tile inside a workgroup, of which only 3 overlap on a CU.  Round 2
-// shortened that chain (ISA of the first version in DESIGN.md finding 12), 231 -> 208 us on the 128 x 128 blocks:
+// shortened that chain (ISA of the first version in FINDINGS.md finding 12), 231 -> 208 us on the 128 x 128 blocks:
 //   * the window registers hold RAW loads; the zero padding is applied from a bit mask when the window is consumed,
 //     one tile later.  A select next to the load made every wave wait for its 18 loads inside the "prefetch";
 //   * the shortcut values are read from LDS in one batch before the epilogue arithmetic (an `if (has_sc) v += St[..]`

@@ -21,7 +21,7 @@
 #include "common.h"
 
 #ifndef FP_PAIR_ABLATE
-#define FP_PAIR_ABLATE 0   // lab only (DESIGN finding 31): 1 no per-row barrier, 2 no MFMAs, 4 no depthwise FMAs, 8 no row loads / stores,
+#define FP_PAIR_ABLATE 0   // lab only (FINDINGS.md finding 31): 1 no per-row barrier, 2 no MFMAs, 4 no depthwise FMAs, 8 no row loads / stores,
                            // 16 block 2 reads one ring row instead of three, 32 no LDS round trip of the output row, 64 depthwise taps not
                            // re-read from LDS -- wrong results, timing only
 #endif

@@ -6,7 +6,7 @@
 // what the BlazeFace planner uses wherever it can keep a tensor in the row-padded layout: blazeblock_wp_kernel for the
 // 24 -> 24 blocks on 128 x 128 / 64 x 64 maps (55 % of the back model's bytes) and blazeblock_wps_kernel for the
 // 48 -> 48 / 96 -> 96 blocks on 32 x 32 / 16 x 16 maps.  Both give a WAVE a tile of 32 pixels end to end (window ->
-// depthwise -> LDS -> MFMA 1x1 -> shortcut -> ReLU -> store) with no workgroup barrier in the loop; DESIGN.md findings
+// depthwise -> LDS -> MFMA 1x1 -> shortcut -> ReLU -> store) with no workgroup barrier in the loop; FINDINGS.md findings
 // 14-15 record what that bought and why.
 #include "common.h"
 
@@ -18,7 +18,7 @@ namespace {
 // The persistent workgroup kernel (blaze.hip) synchronises four waves twice per tile and spends ~390 VALU instructions per wave and
 // tile, most of them on what the padded layout makes unnecessary: clamps, validity masks and selects for the zero
 // padding, per-lane index decode.  With no memory traffic at all its skeleton still takes 140 of its 207 us on the
-// 128 x 128 blocks (lab toggles, DESIGN.md finding 14).  Here
+// 128 x 128 blocks (lab toggles, FINDINGS.md finding 14).  Here
 //   * a WAVE owns a tile of 32 consecutive pixels of one image row and runs the whole chain on it with its own LDS
 //     region: window -> depthwise (48 of 64 lanes = 8 pixel groups x 6 channel groups) -> A tile -> 12 MFMAs against
 //     the 1x1 weights held in registers -> shortcut + ReLU -> output tile -> 3 x 16-byte stores per lane.  No
@@ -49,7 +49,7 @@ struct BlazeWpArgs {
 // ONE new row of 6 loads instead of 18 (R = 4: 9 loads per output row on average).  The window loads, not HBM, were
 // the slow part of the first form of this kernel: with the compute stripped it took 150 us to read a 403 MB tensor that
 // a linear read gets through in 107 us -- 4.5 16-byte requests per output (pixel, channel-quad) in 96-byte pieces keep
-// the CU's address/L1 path busy, and 12 waves x 10 KB of window do not fit the 32 KB L1 (DESIGN.md finding 14).
+// the CU's address/L1 path busy, and 12 waves x 10 KB of window do not fit the 32 KB L1 (FINDINGS.md finding 14).
 template <int C, int R>
 __global__ __launch_bounds__(256, 3) void blazeblock_wp_kernel(BlazeWpArgs p) {
   static_assert(C % 8 == 0 && C <= 32, "one 32-column n tile, K a multiple of 8");

@@ -4,7 +4,7 @@
 // Depth_Wise.forward (fde/modules/mobile_facenet/mobile_facenet.py:77-88):
 //     conv (1x1 expand C -> G, BN, PReLU) -> conv_dw (3x3 depthwise, BN, PReLU) -> project (1x1 G -> C, BN) [+ x].
 // dwblock.hip (fp32 MFMA) showed that the fused block is bound by vector-ALU issue: the fp32 MFMA IS a vector-ALU
-// instruction (DESIGN finding 18).  Here both 1x1 convs run on v_mfma_f32_16x16x32_bf16, the depthwise conv and the
+// instruction (FINDINGS.md finding 18).  Here both 1x1 convs run on v_mfma_f32_16x16x32_bf16, the depthwise conv and the
 // operand split run on the VALU beside them, and the expanded tensor still never leaves the CU.
 //
 //   tile      = 7 output rows of one image (14x14: two bands, 28x28: four) = one 256-thread workgroup; two workgroups

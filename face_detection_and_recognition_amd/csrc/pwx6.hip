@@ -2,7 +2,7 @@
 //
 // The 1x1 convs with K >= 128 input channels (YOLOv5-face's C3 / ShuffleV2 / PAN convs, y5/models/common.py:35-56,127-176;
 // Mobile-FaceNet's conv_6_sep, mobile_facenet.py:131) are bound by the fp32 MFMA in conv_igemm_kernel (~100 TFLOP/s =
-// 65 % of the 157 TFLOP/s fp32 matrix peak, which is the fp32 VECTOR rate, DESIGN finding 18).  Here the fp32 operands are
+// 65 % of the 157 TFLOP/s fp32 matrix peak, which is the fp32 VECTOR rate, FINDINGS.md finding 18).  Here the fp32 operands are
 // split exactly into three bf16 pieces each and multiplied as six bf16 MFMAs per product (fp32 accumulation, csrc/split.h):
 //   * a workgroup = 4 waves owns 256 consecutive rows (pixels) x one chunk of <= 128 output channels; a wave owns 64 rows
 //     (four 16-row MFMA tiles) for ALL of the chunk's columns: accumulators 4 x 8 x 4 registers, A split ONCE per element;

@@ -1,7 +1,7 @@
 // split.h — fp32 operands on the bf16 matrix cores: the exact three-way split ("bf16x6") shared by the *_x6 kernels.
 //
 // gfx950 has no TF32 / xf32 MFMA, and its fp32 MFMA runs at the fp32 VECTOR rate on the vector ALU (64 FLOP/clk/SIMD,
-// 157 TFLOP/s; DESIGN finding 18: it does not even overlap with VALU work), while v_mfma_f32_16x16x32_bf16 delivers
+// 157 TFLOP/s; FINDINGS.md finding 18: it does not even overlap with VALU work), while v_mfma_f32_16x16x32_bf16 delivers
 // 1024 FLOP/clk/SIMD on the matrix core beside the VALU.  An fp32 number has 24 significant bits = three bf16 pieces
 // of 8 bits each, cut by ROUND-TO-NEAREST-EVEN conversions (v_cvt_pk_bf16_f32, one instruction per two values):
 //     h = bf16(x),  m = bf16(x - h),  l = bf16((x - h) - m)        x == h + m + l  EXACTLY

@@ -192,7 +192,7 @@ class BlazeFace(nn.Module):
         # True: this network's plans run BESIDE another network's kernels (FacePipeline(two_streams=True)).  Ops whose
         # workgroups own a whole CU are then not emitted: FP_OP_BLAZECHAIN holds 157 KB of LDS, so for its 75 us nothing of
         # the other stream fits on the CUs and its own launch waits for them to drain -- measured 4.10 against 4.01 ms
-        # per two-stream step, although the detector alone gets 0.19 ms faster with it (DESIGN finding 30).
+        # per two-stream step, although the detector alone gets 0.19 ms faster with it (FINDINGS.md finding 30).
         self.co_scheduled = False
         self._define_layers()
 

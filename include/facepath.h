@@ -159,16 +159,18 @@ typedef struct fp_op {
 #define FP_OPF_IN_C3 4
 /*
  * FP_OPF_SPLIT3 (ABI 5) : the op's 1x1-conv weight matrices are packed as THREE bf16 planes (the exact three-way split
- *                of every fp32 weight, w == h + m + l, planes = the top 16 bits of h, m, l) for the "bf16x6" kernels:
- *                fp32 operands on v_mfma_f32_16x16x32_bf16, six products per operand pair, fp32 accumulation, result as
- *                accurate as the fp32 fmaf chain (csrc/split.h; gfx950 has no TF32 and its fp32 MFMA runs at the
- *                vector rate).  Accepted (exactly fp_plan_validate's list): FP_OP_DWBLOCK stride 1 with (Cin, H = W) in
+ *                of every fp32 weight, w == h + m + l with h = bf16(w), m = bf16(w - h), l = bf16(w - h - m), every conversion
+ *                round-to-nearest-even; planes = the bf16 bit patterns of h, m, l) for the "bf16x6" kernels: fp32 operands on
+ *                v_mfma_f32_16x16x32_bf16, six products per operand pair, fp32 accumulation; the three dropped products are
+ *                < 2^-22.99 of a product and carry either sign (csrc/split.h; gfx950 has no TF32 and its fp32 MFMA runs at
+ *                the vector rate).  Accepted (exactly fp_plan_validate's list): FP_OP_DWBLOCK stride 1 with (Cin, H = W) in
  *                {(128, 14), (128, 7), (64, 28)} and stride 2 with (Cin, Cmid, Cout, H) in {(64, 128, 64, 56),
  *                (64, 256, 128, 28), (128, 512, 128, 14)} (layouts under "DWBLOCK"); FP_OP_CONV 1x1 stride 1 or 3x3 pad 1
  *                stride 1 / 2, dense views, Cin and Cout multiples of 4 and >= 32, or 3x3 with Cin 8 / 16 / 24 (K flattened: k = tap * Cin
  *                + channel in slabs of 32) (weights [tap * ceil(Cin / 32) + slab][3
  *                planes][Npad][32] bf16, zero rows / columns in the padding); FP_OP_DWPW 3x3 pad 1 with Cin a multiple of
- *                32 (<= 256) and Cout 64 or 128; FP_OP_BLAZECHAIN (always).  The semantics of the ops do not change.
+ *                32 (<= 256) and Cout 64 or 128; FP_OP_BLAZECHAIN (always); FP_OP_CONV with
+ *                FP_OPF_OUT_DW (planes [Cout / 16][3][16][32] over k = tap * 3 + channel).  The semantics of the ops do not change.
  */
 #define FP_OPF_SPLIT3 8
 /*

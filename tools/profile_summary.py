@@ -30,12 +30,19 @@ def main():
     stats = list(csv.DictReader(open(ks)))
 
     def pmc(d):
+        """kernel -> [counter sum, launches] of the kernel's LARGEST launches (by grid size): since round 4 the embedder's
+        kernels are launched twice per step -- on the first 512 crops and on the remainder of ~16 (pipeline._embed_split) -- and
+        a per-launch figure must not average the two."""
         f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
-        agg = collections.defaultdict(lambda: [0.0, 0])
+        groups = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
-            a = agg[short(r["Kernel_Name"])]
+            a = groups[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
+        agg = {}
+        for (name, grid), a in groups.items():
+            if name not in agg or grid > agg[name][2]:
+                agg[name] = [a[0], a[1], grid]
         return agg
 
     fe, wr = pmc(fetch_dir), pmc(write_dir)
@@ -43,7 +50,7 @@ def main():
     for k in fe:
         if k in wr and fe[k][1] and wr[k][1]:
             f_kib, w_kib = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
-            traffic[k] = {"launches_profiled": fe[k][1], "FETCH_SIZE_KiB_avg": round(f_kib, 1),
+            traffic[k] = {"launches_profiled": fe[k][1], "grid_size": fe[k][2], "FETCH_SIZE_KiB_avg": round(f_kib, 1),
                           "WRITE_SIZE_KiB_avg": round(w_kib, 1),
                           "hbm_bytes_per_launch": int((2.0 * f_kib + w_kib) * 1024)}
     json.dump(traffic, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
@@ -56,8 +63,10 @@ def main():
         o.write("\n`at::native::*copy*` / `__amd_rocclr_copyBuffer` / `fillBuffer*` rows with thousands of calls are SETUP (the synthetic "
                 "weights and frame batches uploaded tensor by tensor before the first step), not part of a step: a step launches "
                 "about 70 kernels, four of them torch's.\n")
-        o.write("\nPMC (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, KiB, per launch average; "
-                "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the x2 being the gfx950 FETCH_SIZE correction):\n\n")
+        o.write("\nThe embedder's kernels appear twice per step: on the first 512 crops and, on a side stream, on the remainder of "
+                "~16 crops (pipeline._embed_split); `avg us` above averages both kinds of launch.\n")
+        o.write("\nPMC (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, KiB, per launch average over a kernel's "
+                "LARGEST-grid launches; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the x2 being the gfx950 FETCH_SIZE correction):\n\n")
         o.write("| kernel | FETCH KiB | WRITE KiB | HBM MB / launch |\n|---|---|---|---|\n")
         for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_profiled"])[:16]:
             o.write(f"| `{k}` | {v['FETCH_SIZE_KiB_avg']} | {v['WRITE_SIZE_KiB_avg']} | {v['hbm_bytes_per_launch'] / 1e6:.1f} |\n")
