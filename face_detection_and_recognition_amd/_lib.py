@@ -59,6 +59,15 @@ class FpResizeItem(C.Structure):
                 ("dx", C.c_int32), ("dy", C.c_int32), ("dw", C.c_int32), ("dh", C.c_int32)]
 
 
+class FpJpegInfo(C.Structure):
+    """Mirror of struct fp_jpeg_info."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32), ("restart_interval", C.c_int32),
+                ("hs", C.c_int32 * 3), ("vs", C.c_int32 * 3), ("td", C.c_int32 * 3), ("ta", C.c_int32 * 3),
+                ("mcux", C.c_int32), ("mcuy", C.c_int32), ("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3),
+                ("comp_w", C.c_int32 * 3), ("comp_h", C.c_int32 * 3), ("coef_off", C.c_int64 * 3), ("n_coefs", C.c_int64),
+                ("quant", (C.c_uint16 * 64) * 3)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -101,6 +110,10 @@ SIGNATURES = {
     "fp_l2_filter": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P]),
     "fp_resize_standardize": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P]),
     "fp_crop_resize_f32": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),
+    "fp_jpeg_parse": (_I, [_P, _SZ, C.POINTER(FpJpegInfo)]),
+    "fp_jpeg_entropy_decode": (_I, [_P, _SZ, C.POINTER(FpJpegInfo), _P]),
+    "fp_jpeg_workspace_bytes": (_SZ, [C.POINTER(FpJpegInfo)]),
+    "fp_jpeg_reconstruct": (_I, [_P, C.POINTER(FpJpegInfo), _P, _SZ, _P, _I, _P]),
     "fp_tracker_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
 }
 

@@ -40,6 +40,7 @@ def load_net(model_path: str, model_type: str, device: str):
 class BlazeFaceModel(Model):
 
     __slots__ = ["net", "runtime", "model_type"]
+    accepts_device_frames = True     # __call__ / predict_batch take (H, W, 3) / (B, H, W, 3) u8 BGR CUDA tensors as well as numpy
 
     def __init__(self, model_path: str, det_thres: float, bbox_area_thres: float, model_type: str,
                  device: str = "cuda", net: BlazeFace = None):

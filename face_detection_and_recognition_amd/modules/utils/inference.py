@@ -28,17 +28,25 @@ def get_dets_bboxes_confs_lmarks_areas(dets: np.ndarray, orig_size: Tuple[int, i
                                   bbox_lmarks=dets[:, 4:], bbox_labels=opt_labels)
 
 
-def load_image(path: str) -> np.ndarray:
-    """BGR HWC u8 like cv2.imread (PIL decode; cv2 is not a dependency of this build)."""
-    from PIL import Image
+def load_image(path: str, device=None):
+    """BGR HWC u8 like cv2.imread (inference.py:68-76).  device = a HIP device: the frame is decoded there (baseline JPEGs:
+    host Huffman + device reconstruction, modules/utils/jpeg.py, byte-identical to libjpeg-turbo) and returned as a device
+    tensor; device = None: numpy array decoded by Pillow on the host (cv2 is not a dependency of this build)."""
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} does not exist")
+    if device is not None:
+        from .jpeg import imread
+        return imread(path, device, bgr=True)
+    from PIL import Image
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[..., ::-1])
 
 
 def inference_img(net: Model, img, waitKey_val: int = 0) -> PostProcessedDetection:
     """inference.py:61-93 without the drawing/imshow tail."""
-    image = load_image(img) if isinstance(img, str) else img
+    # a net that takes device frames gets the file decoded ON its device (baseline JPEG: host Huffman + device IDCT / upsampling
+    # / colour conversion, byte-identical to cv2.imread's libjpeg-turbo); everything else the host array, as the reference
+    dev = net.net._device() if getattr(net, "accepts_device_frames", False) else None
+    image = load_image(img, dev if dev is not None and dev.type == "cuda" else None) if isinstance(img, str) else img
     h, w = image.shape[:2]
     dets = net(image)
     labels = None

@@ -517,6 +517,46 @@ int fp_tracker_step(float* feats, int* bboxes, int* count, int cap, int D, const
                     const int* new_bboxes, int F, int mode, float normal_thres, float harsh_thres,
                     int* ids, uint8_t* exists, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* 7. JPEG decode (the step in front of the path)           */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Baseline JPEG decode, byte-identical to libjpeg-turbo's default decompressor -- what cv2.imread
+ * (fde/modules/utils/inference.py:68-76, fde/face_extraction/extract_faces_from_dataset.py:393-420) and Pillow return.
+ * Split as hardware decoders split it: marker parsing and Huffman decoding on the HOST (serial per scan; plain C, no GPU:
+ * fp_jpeg_parse, fp_jpeg_entropy_decode -- run one thread per image), everything after it on the DEVICE
+ * (fp_jpeg_reconstruct: dequantisation + the "islow" integer inverse DCT of jidctint.c, fancy chroma upsampling of
+ * jdsample.c for 4:2:0 / 4:2:2, YCbCr -> RGB of jdcolor.c, csrc/jpeg.hip).  Accepted: SOF0 / SOF1 (sequential, 8-bit, Huffman),
+ * one interleaved scan, 1 or 3 components, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals.  Everything
+ * else (progressive, arithmetic, 12-bit, CMYK, multi-scan): FP_ERR_UNSUPPORTED, the caller decodes those on the host.
+ */
+typedef struct fp_jpeg_info {
+  int32_t width, height, ncomp, restart_interval;
+  int32_t hs[3], vs[3];               /* sampling factors */
+  int32_t td[3], ta[3];               /* Huffman table selectors of the scan */
+  int32_t mcux, mcuy;                 /* MCUs per row / column */
+  int32_t blocks_w[3], blocks_h[3];   /* 8 x 8 blocks per component, padded to whole MCUs */
+  int32_t comp_w[3], comp_h[3];       /* a component's true size: ceil(image * samp / max samp) */
+  int64_t coef_off[3];                /* component c: coefs + coef_off[c], [blocks_h][blocks_w][64] int16, natural (row-major) order */
+  int64_t n_coefs;                    /* total int16 coefficients */
+  uint16_t quant[3][64];              /* quantisation table of each component, natural order */
+} fp_jpeg_info;
+
+/* HOST.  Parses the markers up to the scan header. */
+int fp_jpeg_parse(const uint8_t* data, size_t n, fp_jpeg_info* info);
+/* HOST.  Huffman-decodes the scan into coefs (HOST memory, info->n_coefs int16: quantised, de-zigzagged). */
+int fp_jpeg_entropy_decode(const uint8_t* data, size_t n, const fp_jpeg_info* info, int16_t* coefs);
+/* Bytes of device workspace fp_jpeg_reconstruct needs (the components' sample planes). */
+size_t fp_jpeg_workspace_bytes(const fp_jpeg_info* info);
+/*
+ * DEVICE.  coefs: the coefficients in DEVICE memory; info: HOST struct (passed by value to the kernels); workspace:
+ * device, 8-byte aligned; out: device u8 [height][width][3], RGB (bgr = 0) or BGR (bgr = 1, cv2.imread's order);
+ * a one-component image is replicated into the three channels (cv2.imread's default IMREAD_COLOR).
+ */
+int fp_jpeg_reconstruct(const int16_t* coefs, const fp_jpeg_info* info, uint8_t* workspace, size_t ws_bytes, uint8_t* out,
+                        int bgr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

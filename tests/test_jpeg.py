@@ -1,0 +1,155 @@
+"""JPEG decode in front of the path (csrc/jpeg.hip, modules/utils/jpeg.py).
+
+Pin: libjpeg-turbo itself, through Pillow (oracle/jpeg_ref.decode_pil) -- the library family cv2.imread wraps in the reference
+(fde/modules/utils/inference.py:68-76).  tests/golden/jpeg holds the reference's own test images (data fixtures) and the sha256
+of Pillow's decode of each, recorded in the build container (tools/gen_golden.py jpeg).
+  CPU:  the product's HOST half (fp_jpeg_parse / fp_jpeg_entropy_decode, plain C) + the oracle's numpy restatement of the
+        device half against Pillow, byte for byte; refusals; damaged input.
+  GPU:  the product's device half (fp_jpeg_reconstruct) against Pillow and against the oracle restatement, byte for byte.
+cv2.resize after the decode stays parity-unpinned (cv2 is absent offline): that part of the row is unchanged."""
+import ctypes
+import glob
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from face_detection_and_recognition_amd import _lib as L
+from oracle import jpeg_ref
+
+JDIR = os.path.join(ROOT, "tests", "golden", "jpeg")
+EXPECTED = json.load(open(os.path.join(JDIR, "expected.json")))
+BASELINE = ["ref_test2_faces_3.jpg", "ref_test1_faces_0.jpg", "ref_selfie3.jpeg"]
+
+
+def _host_decode(lib, data):
+    info = L.FpJpegInfo()
+    buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
+    rc = lib.fp_jpeg_parse(buf, len(data), ctypes.byref(info))
+    if rc:
+        return rc, info, None
+    coefs = np.zeros(int(info.n_coefs), np.int16)
+    rc = lib.fp_jpeg_entropy_decode(buf, len(data), ctypes.byref(info), coefs.ctypes.data_as(ctypes.c_void_p))
+    return rc, info, coefs
+
+
+def _synthetic(rng, w, h, **kw):
+    """A smooth random image encoded by Pillow (libjpeg-turbo's compressor) with the given options."""
+    from PIL import Image
+    img = np.clip(np.cumsum(np.cumsum(rng.normal(0, 3, (h, w, 3)), 0), 1) + 128, 0, 255).astype(np.uint8)
+    gray = kw.pop("gray", False)
+    b = io.BytesIO()
+    Image.fromarray(img[..., 0] if gray else img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+SYNTH = [(w, h, dict(quality=q, subsampling=sub, **({"restart_marker_blocks": rst} if rst else {})))
+         for (w, h) in ((64, 48), (67, 45), (1, 1), (17, 9), (250, 131))
+         for sub in (0, 1, 2) for q, rst in ((30, 0), (92, 3))] + [(33, 70, dict(quality=75, gray=True)), (8, 8, dict(quality=100, subsampling=2))]
+
+
+def test_pillow_still_decodes_the_fixtures_as_recorded():
+    """The pin itself: libjpeg-turbo (through the Pillow of whatever box runs this) decodes the reference's test images to the
+    bytes recorded in the build container.  If this fails the library under the oracle changed, not the product."""
+    for name, exp in EXPECTED.items():
+        a = jpeg_ref.decode_pil(open(os.path.join(JDIR, name), "rb").read())
+        assert list(a.shape) == exp["shape"] and hashlib.sha256(a.tobytes()).hexdigest() == exp["sha256_rgb"], name
+
+
+def test_host_huffman_and_oracle_restatement_vs_pillow(lib):
+    """fp_jpeg_parse + fp_jpeg_entropy_decode (the product's host half) feed oracle/jpeg_ref.reconstruct (numpy restatement of
+    jidctint.c islow IDCT, jdsample.c fancy upsampling, jdcolor.c): identical, byte for byte, to Pillow's decode -- the
+    reference's 4:2:0 test images and synthetic files over 4:4:4 / 4:2:2 / 4:2:0, odd sizes down to 1 x 1, two qualities,
+    restart intervals, grayscale."""
+    for name in BASELINE:
+        data = open(os.path.join(JDIR, name), "rb").read()
+        rc, info, coefs = _host_decode(lib, data)
+        assert rc == 0, (name, rc)
+        assert [info.height, info.width, 3] == EXPECTED[name]["shape"] and (info.hs[0], info.vs[0]) == (2, 2)
+        got = jpeg_ref.reconstruct(info, coefs)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == EXPECTED[name]["sha256_rgb"], name
+    rng = np.random.default_rng(0)
+    for w, h, kw in SYNTH:
+        data = _synthetic(rng, w, h, **dict(kw))
+        rc, info, coefs = _host_decode(lib, data)
+        assert rc == 0, (w, h, kw, rc)
+        np.testing.assert_array_equal(jpeg_ref.reconstruct(info, coefs), jpeg_ref.decode_pil(data), err_msg=str((w, h, kw)))
+
+
+def test_jpeg_refusals_and_damaged_input(lib):
+    """Progressive files are refused with FP_ERR_UNSUPPORTED (the caller decodes them on the host), non-JPEG bytes and truncated
+    headers with FP_ERR_INVALID_ARG; a scan cut short or with garbage in it never reads outside the buffer and returns either
+    an error or a full-size coefficient set (libjpeg also pads a short scan)."""
+    data = open(os.path.join(JDIR, "ref_selfie1_progressive.jpeg"), "rb").read()
+    assert _host_decode(lib, data)[0] == -3
+    assert _host_decode(lib, b"\x89PNG\r\n\x1a\n" + bytes(64))[0] == -1
+    good = open(os.path.join(JDIR, "ref_selfie3.jpeg"), "rb").read()
+    assert _host_decode(lib, good[:40])[0] == -1
+    rng = np.random.default_rng(1)
+    for cut in (len(good) // 2, len(good) - 3, 700):
+        rc, info, coefs = _host_decode(lib, good[:cut])
+        assert rc in (0, -1)
+    noisy = bytearray(good)
+    for i in rng.integers(700, len(good) - 2, 40):
+        noisy[int(i)] = int(rng.integers(0, 256))
+    assert _host_decode(lib, bytes(noisy))[0] in (0, -1)
+
+
+@pytest.mark.gpu
+def test_jpeg_device_reconstruction_is_byte_identical_to_libjpeg_turbo(dev, lib):
+    """decode_jpeg (host Huffman -> device dequantise + islow IDCT + fancy upsampling + YCbCr -> RGB) == Pillow's decode, byte
+    for byte: the reference's own test images (the sha256 recorded in the build container too) and the synthetic set."""
+    from face_detection_and_recognition_amd.modules.utils import jpeg as J
+    for name in BASELINE:
+        data = open(os.path.join(JDIR, name), "rb").read()
+        got = J.decode_jpeg(data, dev, bgr=False).cpu().numpy()
+        assert hashlib.sha256(got.tobytes()).hexdigest() == EXPECTED[name]["sha256_rgb"], name
+        np.testing.assert_array_equal(got, jpeg_ref.decode_pil(data))
+        bgr = J.decode_jpeg(data, dev).cpu().numpy()                       # cv2.imread's channel order
+        np.testing.assert_array_equal(bgr[..., ::-1], got)
+    rng = np.random.default_rng(0)
+    for w, h, kw in SYNTH:
+        data = _synthetic(rng, w, h, **dict(kw))
+        got = J.decode_jpeg(data, dev, bgr=False).cpu().numpy()
+        np.testing.assert_array_equal(got, jpeg_ref.decode_pil(data), err_msg=str((w, h, kw)))
+        rc, info, coefs = _host_decode(lib, data)
+        np.testing.assert_array_equal(got, jpeg_ref.reconstruct(info, coefs))
+
+
+@pytest.mark.gpu
+def test_jpeg_batch_imread_and_entry_point(dev, tmp_path):
+    """decode_jpeg_batch (Huffman on a thread pool, frames of different sizes), imread (baseline on the device, a progressive
+    file through the host fallback: same pixels as Pillow either way) and the drop-in entry: inference_img on a JPEG path with
+    a BlazeFaceModel decodes on the detector's device and returns what the host-decoded array returns."""
+    from face_detection_and_recognition_amd import workload as W
+    from face_detection_and_recognition_amd.modules.utils import jpeg as J
+    from face_detection_and_recognition_amd.modules.utils.inference import inference_img, load_image
+    names = BASELINE + BASELINE[:1]
+    datas = [open(os.path.join(JDIR, n), "rb").read() for n in names]
+    outs = J.decode_jpeg_batch(datas, dev, bgr=False, threads=3)
+    for n, o in zip(names, outs):
+        assert hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest() == EXPECTED[n]["sha256_rgb"], n
+    with pytest.raises(J.JpegUnsupported):
+        J.decode_jpeg(open(os.path.join(JDIR, "ref_selfie1_progressive.jpeg"), "rb").read(), dev)
+    for n in EXPECTED:
+        path = os.path.join(JDIR, n)
+        img = J.imread(path, dev)
+        assert img.is_cuda and img.dtype == torch.uint8
+        np.testing.assert_array_equal(img.cpu().numpy(), load_image(path))      # == the host (Pillow) BGR array
+    same = [os.path.join(JDIR, "ref_test2_faces_3.jpg")] * 3
+    stacked = J.imread_batch(same, dev)
+    assert isinstance(stacked, torch.Tensor) and tuple(stacked.shape) == (3, 540, 720, 3)
+    np.testing.assert_array_equal(stacked[2].cpu().numpy(), load_image(same[0]))
+    mixed = J.imread_batch([os.path.join(JDIR, n) for n in sorted(EXPECTED)], dev)     # different sizes, one progressive: a list
+    assert isinstance(mixed, list) and [list(t.shape) for t in mixed] == [EXPECTED[n]["shape"] for n in sorted(EXPECTED)]
+    det = W.build_detector(dev, W.make_frames(8, dev, seed=8), cand_per_frame=48)
+    path = os.path.join(JDIR, "ref_test2_faces_3.jpg")
+    a = inference_img(det, path)                                               # decoded on the device
+    b = inference_img(det, load_image(path))                                   # host array, as the reference passes it
+    np.testing.assert_array_equal(a.boxes, b.boxes)
+    np.testing.assert_array_equal(a.bbox_confs, b.bbox_confs)

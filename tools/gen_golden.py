@@ -20,6 +20,7 @@ import ref_harness as rh  # noqa: E402
 from face_detection_and_recognition_amd.synth import synth_state_dict  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
+FDE = "/root/reference/face_detection_and_extraction"
 torch.set_num_threads(4)
 torch.manual_seed(0)
 
@@ -307,6 +308,29 @@ def gen_yolo_blocks():
     save("yolo_bboxes_confs_areas", dets=dets, boxes=boxes, confs=confs, areas=areas)
 
 
+def gen_jpeg():
+    """tests/golden/jpeg: the reference's own test / example JPEGs (data files: fde/data/TEST/test1_faces_0.jpg,
+    test2_faces_3.jpg -- the images its tests run on -- and two of fde/data/EXAMPLE *, one of them progressive) copied as INPUT
+    fixtures, and the sha256 of what libjpeg-turbo (through Pillow, in this container) decodes them to: the pin of
+    oracle/jpeg_ref.py and of the product's decoder (csrc/jpeg.hip)."""
+    import hashlib
+    import json
+    import shutil
+    from oracle import jpeg_ref
+    src = {"ref_test1_faces_0.jpg": "data/TEST/test1_faces_0.jpg", "ref_test2_faces_3.jpg": "data/TEST/test2_faces_3.jpg",
+           "ref_selfie3.jpeg": "data/EXAMPLE 2/selfie3.jpeg", "ref_selfie1_progressive.jpeg": "data/EXAMPLE 1/selfie1.jpeg"}
+    out = os.path.join(OUT, "jpeg")
+    os.makedirs(out, exist_ok=True)
+    exp = {}
+    for name, rel in src.items():
+        dst = os.path.join(out, name)
+        shutil.copyfile(os.path.join(FDE, rel), dst)
+        a = jpeg_ref.decode_pil(open(dst, "rb").read())
+        exp[name] = {"shape": list(a.shape), "sha256_rgb": hashlib.sha256(a.tobytes()).hexdigest(), "mean": round(float(a.mean()), 4)}
+    json.dump(exp, open(os.path.join(out, "expected.json"), "w"), indent=1, sort_keys=True)
+    print("jpeg:", {k: v["shape"] for k, v in exp.items()})
+
+
 def gen_tracker():
     """Face-tracker matching: the reference's own Net.check_if_face_exists / Net.add_face
     (fde/face_extraction/extract_and_label_faces_from_dataset.py:101-121) on seeded feature / box sequences.  The module
@@ -396,3 +420,5 @@ if __name__ == "__main__":
         gen_tracker()
     if "yolo_blocks" in which:      # added in round 2; not part of the default list so the round-1 files stay untouched
         gen_yolo_blocks()
+    if "jpeg" in which:             # round 4
+        gen_jpeg()
