@@ -62,7 +62,7 @@ class FpResizeItem(C.Structure):
 class FpJpegInfo(C.Structure):
     """Mirror of struct fp_jpeg_info."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32), ("restart_interval", C.c_int32),
-                ("hs", C.c_int32 * 3), ("vs", C.c_int32 * 3), ("td", C.c_int32 * 3), ("ta", C.c_int32 * 3),
+                ("progressive", C.c_int32), ("reserved", C.c_int32), ("hs", C.c_int32 * 3), ("vs", C.c_int32 * 3),
                 ("mcux", C.c_int32), ("mcuy", C.c_int32), ("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3),
                 ("comp_w", C.c_int32 * 3), ("comp_h", C.c_int32 * 3), ("coef_off", C.c_int64 * 3), ("n_coefs", C.c_int64),
                 ("quant", (C.c_uint16 * 64) * 3)]

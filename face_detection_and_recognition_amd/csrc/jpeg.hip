@@ -1,4 +1,5 @@
-// jpeg.hip — baseline JPEG decode, bit-exact with libjpeg-turbo's default decompressor (gfx950 + host).
+// jpeg.hip — JPEG decode (sequential and progressive Huffman files), bit-exact with libjpeg-turbo's default decompressor
+// (gfx950 + host).
 //
 // The step in FRONT of the hot path: the reference reads its frames with cv2.imread
 // (fde/modules/utils/inference.py:68-76, fde/face_extraction/extract_faces_from_dataset.py:393-420) and tf.io.decode_jpeg
@@ -11,9 +12,10 @@
 //           YCbCr -> RGB in 16-bit fixed point (jdcolor.c) -> interleaved u8 RGB or BGR frame (fp_jpeg_reconstruct)
 // All three device stages are integer arithmetic restated from the library's published algorithm; the result is compared
 // byte for byte with Pillow's decode (libjpeg-turbo) of the reference's own test images (tests/golden/jpeg, tests/test_jpeg.py).
-// Scope: baseline / extended sequential, 8-bit, Huffman, one interleaved scan, 1 or 3 components, luma sampling 1x1 / 2x1 /
-// 2x2 with 1x1 chroma, restart intervals.  Progressive, arithmetic-coded, 12-bit, CMYK and multi-scan files are refused
-// (FP_ERR_UNSUPPORTED): the caller falls back to its host decoder for those.
+// Scope: sequential (SOF0 / SOF1) and PROGRESSIVE (SOF2: spectral selection + successive approximation, jdphuff.c) Huffman
+// files, 8-bit, any number of scans, 1 or 3 components, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals.
+// Arithmetic-coded, lossless, 12-bit, CMYK and other sampling layouts are refused (FP_ERR_UNSUPPORTED): the caller falls back
+// to its host decoder for those.
 #include <string.h>
 
 #include "common.h"
@@ -122,19 +124,121 @@ inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 :
 
 inline unsigned be16(const unsigned char* p) { return ((unsigned)p[0] << 8) | p[1]; }
 
-// Walks the markers up to (and including) SOS; fills info.  Returns the offset of the first entropy-coded byte or a
-// negative fp_status.
-long parse_headers(const unsigned char* d, size_t n, fp_jpeg_info& info, Huff* dc /*[4]*/, Huff* ac /*[4]*/) {
+struct Frame {               // what the frame header (SOF) and the tables in front of the first scan say
+  int comp_id[3], comp_tq[3];
+  unsigned short qt[4][64];
+  bool have_qt[4];
+  bool have_sof;
+};
+
+// DQT / DHT / DRI segment bodies (s .. e)
+int read_dqt(const unsigned char* s, const unsigned char* e, Frame& fr) {
+  while (s < e) {
+    const int pq = s[0] >> 4, tq = s[0] & 15;
+    if (tq > 3 || pq > 1) return FP_ERR_INVALID_ARG;
+    ++s;
+    if (s + (pq ? 128 : 64) > e) return FP_ERR_INVALID_ARG;
+    for (int i = 0; i < 64; ++i) fr.qt[tq][kZigzag[i]] = pq ? (unsigned short)be16(s + 2 * i) : s[i];   // natural order
+    s += pq ? 128 : 64;
+    fr.have_qt[tq] = true;
+  }
+  return FP_OK;
+}
+
+int read_dht(const unsigned char* s, const unsigned char* e, Huff* dc, Huff* ac) {
+  while (s < e) {
+    const int tc = s[0] >> 4, th = s[0] & 15;
+    if (tc > 1 || th > 3 || s + 17 > e) return FP_ERR_INVALID_ARG;
+    unsigned char bits[17];
+    bits[0] = 0;
+    int nv = 0;
+    for (int i = 1; i <= 16; ++i) bits[i] = s[i], nv += s[i];
+    if (nv > 256 || s + 17 + nv > e) return FP_ERR_INVALID_ARG;
+    if (!build_huff(tc ? ac[th] : dc[th], bits, s + 17, nv)) return FP_ERR_INVALID_ARG;
+    s += 17 + nv;
+  }
+  return FP_OK;
+}
+
+int read_sof(const unsigned char* s, unsigned len, unsigned m, fp_jpeg_info& info, Frame& fr) {
+  if (len < 8 || s[0] != 8) return FP_ERR_UNSUPPORTED;       // 8-bit samples only
+  info.progressive = m == 0xc2;
+  info.height = (int)be16(s + 1);
+  info.width = (int)be16(s + 3);
+  info.ncomp = s[5];
+  if (info.width <= 0 || info.height <= 0) return FP_ERR_UNSUPPORTED;
+  if ((info.ncomp != 1 && info.ncomp != 3) || len < 8u + 3u * info.ncomp) return FP_ERR_UNSUPPORTED;
+  for (int c = 0; c < info.ncomp; ++c) {
+    fr.comp_id[c] = s[6 + 3 * c];
+    info.hs[c] = s[7 + 3 * c] >> 4;
+    info.vs[c] = s[7 + 3 * c] & 15;
+    fr.comp_tq[c] = s[8 + 3 * c];
+    if (fr.comp_tq[c] > 3) return FP_ERR_INVALID_ARG;
+  }
+  // geometry: luma 1x1 / 2x1 / 2x2, chroma 1x1
+  if (info.ncomp == 1) {
+    info.hs[0] = info.vs[0] = 1;            // a single-component image is never interleaved: 8 x 8 MCUs
+  } else {
+    if (info.hs[1] != 1 || info.vs[1] != 1 || info.hs[2] != 1 || info.vs[2] != 1) return FP_ERR_UNSUPPORTED;
+    if (!((info.hs[0] == 1 && info.vs[0] == 1) || (info.hs[0] == 2 && info.vs[0] == 1) || (info.hs[0] == 2 && info.vs[0] == 2)))
+      return FP_ERR_UNSUPPORTED;
+  }
+  info.mcux = (info.width + 8 * info.hs[0] - 1) / (8 * info.hs[0]);
+  info.mcuy = (info.height + 8 * info.vs[0] - 1) / (8 * info.vs[0]);
+  long off = 0;
+  for (int c = 0; c < info.ncomp; ++c) {
+    info.blocks_w[c] = info.mcux * info.hs[c];
+    info.blocks_h[c] = info.mcuy * info.vs[c];
+    info.coef_off[c] = off;
+    off += (long)info.blocks_w[c] * info.blocks_h[c] * 64;
+    // the component's true size (jdmaster.c: ceil(image * samp / max_samp)): what the fancy upsampler's edges see
+    info.comp_w[c] = (info.width * info.hs[c] + info.hs[0] - 1) / info.hs[0];
+    info.comp_h[c] = (info.height * info.vs[c] + info.vs[0] - 1) / info.vs[0];
+  }
+  info.n_coefs = off;
+  fr.have_sof = true;
+  return FP_OK;
+}
+
+struct Scan {
+  int ns, ci[3], td[3], ta[3], Ss, Se, Ah, Al;
+};
+
+int read_sos(const unsigned char* s, unsigned len, const fp_jpeg_info& info, const Frame& fr, Scan& sc) {
+  sc.ns = s[0];
+  if (sc.ns < 1 || sc.ns > info.ncomp || len != 6u + 2u * sc.ns) return FP_ERR_INVALID_ARG;
+  for (int i = 0; i < sc.ns; ++i) {
+    int c = 0;
+    while (c < info.ncomp && fr.comp_id[c] != s[1 + 2 * i]) ++c;
+    if (c == info.ncomp) return FP_ERR_INVALID_ARG;
+    sc.ci[i] = c;
+    sc.td[i] = s[2 + 2 * i] >> 4;
+    sc.ta[i] = s[2 + 2 * i] & 15;
+    if (sc.td[i] > 3 || sc.ta[i] > 3) return FP_ERR_INVALID_ARG;
+  }
+  sc.Ss = s[1 + 2 * sc.ns];
+  sc.Se = s[2 + 2 * sc.ns];
+  sc.Ah = s[3 + 2 * sc.ns] >> 4;
+  sc.Al = s[3 + 2 * sc.ns] & 15;
+  if (!info.progressive) {
+    if (sc.Ss != 0 || sc.Se != 63 || sc.Ah != 0 || sc.Al != 0) return FP_ERR_INVALID_ARG;
+  } else {
+    if (sc.Ss > sc.Se || sc.Se > 63 || sc.Al > 13 || (sc.Ss == 0 && sc.Se != 0) || (sc.Ss > 0 && sc.ns != 1)) return FP_ERR_INVALID_ARG;
+    if (sc.Ah != 0 && sc.Ah != sc.Al + 1) return FP_ERR_INVALID_ARG;
+  }
+  return FP_OK;
+}
+
+// Walks the markers up to the first SOS; fills info (frame geometry, quantisation tables).  Returns the offset of that SOS
+// marker's segment length or a negative fp_status.  dc / ac collect the Huffman tables seen on the way.
+long parse_headers(const unsigned char* d, size_t n, fp_jpeg_info& info, Frame& fr, Huff* dc /*[4]*/, Huff* ac /*[4]*/) {
   memset(&info, 0, sizeof(info));
+  memset(&fr, 0, sizeof(fr));
   if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return FP_ERR_INVALID_ARG;
   size_t pos = 2;
-  bool have_sof = false;
-  unsigned short qt[4][64];
-  bool have_qt[4] = {false, false, false, false};
-  int comp_id[3] = {0, 0, 0}, comp_tq[3] = {0, 0, 0};
   while (pos + 4 <= n) {
     if (d[pos] != 0xff) return FP_ERR_INVALID_ARG;
-    unsigned m = d[pos + 1];
+    const unsigned m = d[pos + 1];
     pos += 2;
     if (m == 0xff) {          // fill byte
       --pos;
@@ -147,90 +251,166 @@ long parse_headers(const unsigned char* d, size_t n, fp_jpeg_info& info, Huff* d
     if (len < 2 || pos + len > n) return FP_ERR_INVALID_ARG;
     const unsigned char* s = d + pos + 2;
     const unsigned char* e = d + pos + len;
-    if (m == 0xdb) {          // DQT
-      while (s < e) {
-        const int pq = s[0] >> 4, tq = s[0] & 15;
-        if (tq > 3 || pq > 1) return FP_ERR_INVALID_ARG;
-        ++s;
-        if (s + (pq ? 128 : 64) > e) return FP_ERR_INVALID_ARG;
-        for (int i = 0; i < 64; ++i) {
-          qt[tq][kZigzag[i]] = pq ? (unsigned short)be16(s + 2 * i) : s[i];   // stored in natural order
-        }
-        s += pq ? 128 : 64;
-        have_qt[tq] = true;
-      }
-    } else if (m == 0xc0 || m == 0xc1) {   // SOF0 / SOF1: baseline / extended sequential, Huffman
-      if (len < 8 || s[0] != 8) return FP_ERR_UNSUPPORTED;
-      info.height = (int)be16(s + 1);
-      info.width = (int)be16(s + 3);
-      info.ncomp = s[5];
-      if (info.width <= 0 || info.height <= 0) return FP_ERR_UNSUPPORTED;
-      if ((info.ncomp != 1 && info.ncomp != 3) || len < 8u + 3u * info.ncomp) return FP_ERR_UNSUPPORTED;
-      for (int c = 0; c < info.ncomp; ++c) {
-        comp_id[c] = s[6 + 3 * c];
-        info.hs[c] = s[7 + 3 * c] >> 4;
-        info.vs[c] = s[7 + 3 * c] & 15;
-        comp_tq[c] = s[8 + 3 * c];
-        if (comp_tq[c] > 3) return FP_ERR_INVALID_ARG;
-      }
-      have_sof = true;
-    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-      return FP_ERR_UNSUPPORTED;   // progressive, lossless, arithmetic, differential
-    } else if (m == 0xc4) {   // DHT
-      while (s < e) {
-        const int tc = s[0] >> 4, th = s[0] & 15;
-        if (tc > 1 || th > 3 || s + 17 > e) return FP_ERR_INVALID_ARG;
-        unsigned char bits[17];
-        bits[0] = 0;
-        int nv = 0;
-        for (int i = 1; i <= 16; ++i) bits[i] = s[i], nv += s[i];
-        if (nv > 256 || s + 17 + nv > e) return FP_ERR_INVALID_ARG;
-        if (!build_huff(tc ? ac[th] : dc[th], bits, s + 17, nv)) return FP_ERR_INVALID_ARG;
-        s += 17 + nv;
-      }
-    } else if (m == 0xdd) {   // DRI
+    int rc = FP_OK;
+    if (m == 0xdb) rc = read_dqt(s, e, fr);
+    else if (m == 0xc0 || m == 0xc1 || m == 0xc2) rc = read_sof(s, len, m, info, fr);   // sequential / progressive, Huffman, 8-bit
+    else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) rc = FP_ERR_UNSUPPORTED;   // lossless, arithmetic, differential
+    else if (m == 0xc4) rc = read_dht(s, e, dc, ac);
+    else if (m == 0xdd) {
       if (len != 4) return FP_ERR_INVALID_ARG;
       info.restart_interval = (int)be16(s);
-    } else if (m == 0xda) {   // SOS
-      if (!have_sof) return FP_ERR_INVALID_ARG;
-      const int ns = s[0];
-      if (ns != info.ncomp || len != 6u + 2u * ns) return FP_ERR_UNSUPPORTED;   // one interleaved scan with every component
-      for (int c = 0; c < ns; ++c) {
-        if (s[1 + 2 * c] != comp_id[c]) return FP_ERR_UNSUPPORTED;
-        info.td[c] = s[2 + 2 * c] >> 4;
-        info.ta[c] = s[2 + 2 * c] & 15;
-        if (info.td[c] > 3 || info.ta[c] > 3 || !dc[info.td[c]].present || !ac[info.ta[c]].present) return FP_ERR_INVALID_ARG;
-      }
-      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return FP_ERR_UNSUPPORTED;
-      // geometry: luma 1x1 / 2x1 / 2x2, chroma 1x1
-      if (info.ncomp == 1) {
-        info.hs[0] = info.vs[0] = 1;            // a single-component scan is never interleaved: 8 x 8 MCUs
-      } else {
-        if (info.hs[1] != 1 || info.vs[1] != 1 || info.hs[2] != 1 || info.vs[2] != 1) return FP_ERR_UNSUPPORTED;
-        if (!((info.hs[0] == 1 && info.vs[0] == 1) || (info.hs[0] == 2 && info.vs[0] == 1) ||
-              (info.hs[0] == 2 && info.vs[0] == 2)))
-          return FP_ERR_UNSUPPORTED;
-      }
-      info.mcux = (info.width + 8 * info.hs[0] - 1) / (8 * info.hs[0]);
-      info.mcuy = (info.height + 8 * info.vs[0] - 1) / (8 * info.vs[0]);
-      long off = 0;
+    } else if (m == 0xda) {
+      if (!fr.have_sof) return FP_ERR_INVALID_ARG;
       for (int c = 0; c < info.ncomp; ++c) {
-        if (!have_qt[comp_tq[c]]) return FP_ERR_INVALID_ARG;
-        memcpy(info.quant[c], qt[comp_tq[c]], 128);
-        info.blocks_w[c] = info.mcux * info.hs[c];
-        info.blocks_h[c] = info.mcuy * info.vs[c];
-        info.coef_off[c] = off;
-        off += (long)info.blocks_w[c] * info.blocks_h[c] * 64;
-        // the component's true size (jdmaster.c: ceil(image * samp / max_samp)): what the fancy upsampler's edges see
-        info.comp_w[c] = (info.width * info.hs[c] + info.hs[0] - 1) / info.hs[0];
-        info.comp_h[c] = (info.height * info.vs[c] + info.vs[0] - 1) / info.vs[0];
+        if (!fr.have_qt[fr.comp_tq[c]]) return FP_ERR_INVALID_ARG;
+        memcpy(info.quant[c], fr.qt[fr.comp_tq[c]], 128);
       }
-      info.n_coefs = off;
-      return (long)(pos + len);
+      return (long)pos;
     }
+    if (rc) return rc;
     pos += len;
   }
   return FP_ERR_INVALID_ARG;
+}
+
+// One scan's entropy-coded segment -> coefficients (jdhuff.c decode_mcu for sequential files; jdphuff.c's four MCU decoders for
+// progressive ones: DC first / DC refine / AC first / AC refine).  Returns FP_OK and leaves br at the marker behind the scan.
+int decode_scan(BitReader& br, const fp_jpeg_info& info, const Scan& sc, const Huff* dc, const Huff* ac, int16_t* coefs) {
+  for (int i = 0; i < sc.ns; ++i) {
+    if ((sc.Ss == 0 && sc.Ah == 0 && !dc[sc.td[i]].present) || (sc.Se > 0 && !ac[sc.ta[i]].present)) return FP_ERR_INVALID_ARG;
+  }
+  // MCU geometry: interleaved scans walk the frame's MCUs; a one-component scan walks that component's own blocks
+  const int c0 = sc.ci[0];
+  const bool inter = sc.ns > 1;
+  const int nmx = inter ? info.mcux : (info.comp_w[c0] + 7) / 8;
+  const int nmy = inter ? info.mcuy : (info.comp_h[c0] + 7) / 8;
+  int pred[3] = {0, 0, 0};
+  int eobrun = 0;
+  int until_restart = info.restart_interval, next_rst = 0;
+  const int p1 = 1 << sc.Al, m1 = -(1 << sc.Al);
+  for (int my = 0; my < nmy; ++my) {
+    for (int mx = 0; mx < nmx; ++mx) {
+      if (info.restart_interval && until_restart == 0) {
+        br.nbits = 0;                              // byte-align, expect RSTn
+        br.acc = 0;
+        if (!br.marker) {
+          while (br.p + 1 < br.end && !(br.p[0] == 0xff && br.p[1] != 0 && br.p[1] != 0xff)) ++br.p;
+          if (br.p + 1 < br.end) br.marker = br.p[1];
+        }
+        if (br.marker != 0xd0 + next_rst) return FP_ERR_INVALID_ARG;
+        br.p += 2;
+        br.marker = 0;
+        next_rst = (next_rst + 1) & 7;
+        pred[0] = pred[1] = pred[2] = 0;
+        eobrun = 0;
+        until_restart = info.restart_interval;
+      }
+      for (int i = 0; i < sc.ns; ++i) {
+        const int c = sc.ci[i];
+        const int nv = inter ? info.vs[c] : 1, nh = inter ? info.hs[c] : 1;
+        for (int v = 0; v < nv; ++v) {
+          for (int hh = 0; hh < nh; ++hh) {
+            int16_t* blk = coefs + info.coef_off[c] + ((long)(my * nv + v) * info.blocks_w[c] + (mx * nh + hh)) * 64;
+            if (!info.progressive) {
+              // ---- sequential: DC difference, then run / size pairs up to EOB ----
+              int s = huff_decode(br, dc[sc.td[i]]);
+              if (s < 0 || s > 11) return FP_ERR_INVALID_ARG;
+              if (s) pred[c] += extend(br.get(s), s);
+              blk[0] = (int16_t)pred[c];
+              const Huff& ha = ac[sc.ta[i]];
+              for (int k = 1; k < 64;) {
+                const int rs = huff_decode(br, ha);
+                if (rs < 0) return FP_ERR_INVALID_ARG;
+                const int r = rs >> 4;
+                s = rs & 15;
+                if (s == 0) {
+                  if (r != 15) break;            // EOB
+                  k += 16;
+                  continue;
+                }
+                k += r;
+                if (k > 63) return FP_ERR_INVALID_ARG;
+                blk[kZigzag[k]] = (int16_t)extend(br.get(s), s);
+                ++k;
+              }
+            } else if (sc.Ss == 0) {
+              if (sc.Ah == 0) {                    // ---- DC first scan ----
+                const int s = huff_decode(br, dc[sc.td[i]]);
+                if (s < 0 || s > 11) return FP_ERR_INVALID_ARG;
+                if (s) pred[c] += extend(br.get(s), s);
+                blk[0] = (int16_t)(pred[c] * (1 << sc.Al));
+              } else if (br.get(1)) {              // ---- DC refinement: one more bit ----
+                blk[0] = (int16_t)(blk[0] | p1);
+              }
+            } else if (sc.Ah == 0) {               // ---- AC first scan (one component) ----
+              if (eobrun > 0) {
+                --eobrun;
+              } else {
+                const Huff& ha = ac[sc.ta[i]];
+                for (int k = sc.Ss; k <= sc.Se; ++k) {
+                  const int rs = huff_decode(br, ha);
+                  if (rs < 0) return FP_ERR_INVALID_ARG;
+                  const int r = rs >> 4, s = rs & 15;
+                  if (s) {
+                    k += r;
+                    if (k > 63) return FP_ERR_INVALID_ARG;
+                    blk[kZigzag[k]] = (int16_t)(extend(br.get(s), s) * (1 << sc.Al));
+                  } else if (r == 15) {
+                    k += 15;                       // ZRL
+                  } else {
+                    eobrun = 1 << r;
+                    if (r) eobrun += br.get(r);
+                    --eobrun;
+                    break;
+                  }
+                }
+              }
+            } else {                               // ---- AC refinement scan (one component): jdphuff.c decode_mcu_AC_refine ----
+              const Huff& ha = ac[sc.ta[i]];
+              int k = sc.Ss;
+              if (eobrun == 0) {
+                for (; k <= sc.Se; ++k) {
+                  const int rs = huff_decode(br, ha);
+                  if (rs < 0) return FP_ERR_INVALID_ARG;
+                  int r = rs >> 4, s = rs & 15;
+                  if (s) {
+                    s = br.get(1) ? p1 : m1;       // (size is always 1: the new coefficient's sign)
+                  } else if (r != 15) {
+                    eobrun = 1 << r;
+                    if (r) eobrun += br.get(r);
+                    break;                         // end of band: the rest of the block gets correction bits only
+                  }
+                  // step over r still-zero coefficients, appending a correction bit to every nonzero one on the way
+                  do {
+                    int16_t* t = blk + kZigzag[k];
+                    if (*t != 0) {
+                      if (br.get(1) && (*t & p1) == 0) *t = (int16_t)(*t + (*t >= 0 ? p1 : m1));
+                    } else if (--r < 0) {
+                      break;
+                    }
+                    ++k;
+                  } while (k <= sc.Se);
+                  if (s) {
+                    if (k > 63) return FP_ERR_INVALID_ARG;
+                    blk[kZigzag[k]] = (int16_t)s;
+                  }
+                }
+              }
+              if (eobrun > 0) {
+                for (; k <= sc.Se; ++k) {
+                  int16_t* t = blk + kZigzag[k];
+                  if (*t != 0 && br.get(1) && (*t & p1) == 0) *t = (int16_t)(*t + (*t >= 0 ? p1 : m1));
+                }
+                --eobrun;
+              }
+            }
+          }
+        }
+      }
+      if (info.restart_interval) --until_restart;
+    }
+  }
+  return FP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -397,77 +577,86 @@ extern "C" {
 
 int fp_jpeg_parse(const uint8_t* data, size_t n, fp_jpeg_info* info) {
   if (!data || !info) return FP_ERR_INVALID_ARG;
-  Huff dc[4], ac[4];
-  memset(dc, 0, sizeof(dc));
-  memset(ac, 0, sizeof(ac));
-  const long r = parse_headers(data, n, *info, dc, ac);
+  Huff* tabs = new Huff[8];
+  memset(tabs, 0, 8 * sizeof(Huff));
+  Frame fr;
+  const long r = parse_headers(data, n, *info, fr, tabs, tabs + 4);
+  delete[] tabs;
   return r < 0 ? (int)r : FP_OK;
 }
 
 int fp_jpeg_entropy_decode(const uint8_t* data, size_t n, const fp_jpeg_info* info_in, int16_t* coefs) {
   if (!data || !info_in || !coefs) return FP_ERR_INVALID_ARG;
   fp_jpeg_info info;
-  Huff dc[4], ac[4];
-  memset(dc, 0, sizeof(dc));
-  memset(ac, 0, sizeof(ac));
-  const long start = parse_headers(data, n, info, dc, ac);
-  if (start < 0) return (int)start;
-  if (info.n_coefs != info_in->n_coefs || info.width != info_in->width || info.height != info_in->height) return FP_ERR_INVALID_ARG;
-  memset(coefs, 0, (size_t)info.n_coefs * sizeof(int16_t));
-  BitReader br;
-  br.init(data + start, data + n);
-  int pred[3] = {0, 0, 0};
-  int until_restart = info.restart_interval, next_rst = 0;
-  for (int my = 0; my < info.mcuy; ++my) {
-    for (int mx = 0; mx < info.mcux; ++mx) {
-      if (info.restart_interval && until_restart == 0) {
-        // byte-align, expect RSTn
-        br.nbits = 0;
-        br.acc = 0;
-        if (!br.marker) {
-          // (the reader stops at markers: unread bytes before one can only be padding)
-          while (br.p + 1 < br.end && !(br.p[0] == 0xff && br.p[1] != 0 && br.p[1] != 0xff)) ++br.p;
-          if (br.p + 1 < br.end) br.marker = br.p[1];
-        }
-        if (br.marker != 0xd0 + next_rst) return FP_ERR_INVALID_ARG;
-        br.p += 2;
-        br.marker = 0;
-        next_rst = (next_rst + 1) & 7;
-        pred[0] = pred[1] = pred[2] = 0;
-        until_restart = info.restart_interval;
-      }
-      for (int c = 0; c < info.ncomp; ++c) {
-        const Huff& hd = dc[info.td[c]];
-        const Huff& ha = ac[info.ta[c]];
-        for (int v = 0; v < info.vs[c]; ++v) {
-          for (int hh = 0; hh < info.hs[c]; ++hh) {
-            int16_t* blk = coefs + info.coef_off[c] + ((long)(my * info.vs[c] + v) * info.blocks_w[c] + (mx * info.hs[c] + hh)) * 64;
-            int s = huff_decode(br, hd);
-            if (s < 0 || s > 11) return FP_ERR_INVALID_ARG;
-            if (s) pred[c] += extend(br.get(s), s);
-            blk[0] = (int16_t)pred[c];
-            for (int k = 1; k < 64;) {
-              const int rs = huff_decode(br, ha);
-              if (rs < 0) return FP_ERR_INVALID_ARG;
-              const int r = rs >> 4;
-              s = rs & 15;
-              if (s == 0) {
-                if (r != 15) break;            // EOB
-                k += 16;
-                continue;
-              }
-              k += r;
-              if (k > 63) return FP_ERR_INVALID_ARG;
-              blk[kZigzag[k]] = (int16_t)extend(br.get(s), s);
-              ++k;
-            }
-          }
-        }
-      }
-      if (info.restart_interval) --until_restart;
-    }
+  Huff* dc = new Huff[8];
+  Huff* ac = dc + 4;
+  memset(dc, 0, 8 * sizeof(Huff));
+  Frame fr;
+  long pos = parse_headers(data, n, info, fr, dc, ac);
+  int rc = pos < 0 ? (int)pos : FP_OK;
+  if (!rc && (info.n_coefs != info_in->n_coefs || info.width != info_in->width || info.height != info_in->height)) rc = FP_ERR_INVALID_ARG;
+  if (rc) {
+    delete[] dc;
+    return rc;
   }
-  return FP_OK;
+  memset(coefs, 0, (size_t)info.n_coefs * sizeof(int16_t));
+  // pos = the first SOS segment's length field.  One scan after the other; DHT / DRI (/ DQT, ignored: a component's table is
+  // latched at its first scan) may stand between scans; EOI or the end of the data ends the image.
+  int scans = 0;
+  for (;;) {
+    if ((size_t)pos + 2 > n) break;
+    const unsigned len = be16(data + pos);
+    if (len < 2 || (size_t)pos + len > n) {
+      rc = FP_ERR_INVALID_ARG;
+      break;
+    }
+    Scan sc;
+    rc = read_sos(data + pos + 2, len, info, fr, sc);
+    if (rc) break;
+    BitReader br;
+    br.init(data + pos + len, data + n);
+    rc = decode_scan(br, info, sc, dc, ac, coefs);
+    if (rc) break;
+    ++scans;
+    // the marker behind the scan
+    const unsigned char* p = br.p;
+    if (!br.marker) {
+      while (p + 1 < data + n && !(p[0] == 0xff && p[1] != 0 && p[1] != 0xff)) ++p;
+    }
+    bool next_scan = false;
+    while (p + 1 < data + n) {
+      if (p[0] != 0xff) break;
+      const unsigned m = p[1];
+      if (m == 0xff) {
+        ++p;
+        continue;
+      }
+      if (m == 0xd9) break;                                        // EOI
+      if (m >= 0xd0 && m <= 0xd7) {
+        p += 2;
+        continue;
+      }
+      if (p + 4 > data + n) break;
+      const unsigned l2 = be16(p + 2);
+      if (l2 < 2 || p + 2 + l2 > data + n) {
+        rc = FP_ERR_INVALID_ARG;
+        break;
+      }
+      if (m == 0xc4) rc = read_dht(p + 4, p + 2 + l2, dc, ac);
+      else if (m == 0xdd && l2 == 4) info.restart_interval = (int)be16(p + 4);
+      else if (m == 0xda) {
+        pos = (long)(p + 2 - data);
+        next_scan = true;
+        break;
+      }
+      if (rc) break;
+      p += 2 + l2;
+    }
+    if (rc || !next_scan) break;
+  }
+  delete[] dc;
+  if (rc) return rc;
+  return scans > 0 ? FP_OK : FP_ERR_INVALID_ARG;
 }
 
 size_t fp_jpeg_workspace_bytes(const fp_jpeg_info* info) {

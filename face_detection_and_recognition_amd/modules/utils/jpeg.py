@@ -5,12 +5,12 @@ fde/face_extraction/extract_faces_from_dataset.py:393-420).
     decode_jpeg(data, device)                 one frame  -> (H, W, 3) u8 BGR tensor on `device`
     decode_jpeg_batch(datas, device)          many frames: Huffman decoding on a thread pool (the C function drops the GIL),
                                               coefficient upload and the device kernels on the caller's stream
-    imread(path, device)                      cv2.imread for the device: baseline JPEGs through the above; what the kernels do
-                                              not take (progressive JPEG, PNG, ...) is decoded by Pillow on the host -- file
-                                              I/O, not the hot path -- and uploaded
+    imread(path, device)                      cv2.imread for the device: JPEGs (sequential and progressive) through the above;
+                                              what the decoder does not take (CMYK / arithmetic-coded JPEGs, PNG, ...) is
+                                              decoded by Pillow on the host -- file I/O, not the hot path -- and uploaded
 
-JpegUnsupported is raised by the first two for files outside csrc/jpeg.hip's scope (progressive, arithmetic-coded,
-12-bit, CMYK, multi-scan)."""
+JpegUnsupported is raised by the first two for files outside csrc/jpeg.hip's scope (arithmetic-coded, lossless, 12-bit,
+CMYK, sampling layouts other than 4:4:4 / 4:2:2 / 4:2:0).  All 1048 JPEG files of the reference's tree are inside it."""
 import ctypes as C
 from concurrent.futures import ThreadPoolExecutor
 
@@ -32,7 +32,7 @@ def parse(data):
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     rc = L.load().fp_jpeg_parse(buf, len(data), C.byref(info))
     if rc == FP_ERR_UNSUPPORTED:
-        raise JpegUnsupported("not a baseline JPEG this decoder takes (progressive / arithmetic / 12-bit / CMYK / multi-scan)")
+        raise JpegUnsupported("a JPEG this decoder does not take (arithmetic-coded / lossless / 12-bit / CMYK / unusual sampling)")
     L.check(rc, "fp_jpeg_parse")
     return info, buf
 

@@ -527,14 +527,15 @@ int fp_tracker_step(float* feats, int* bboxes, int* count, int cap, int D, const
  * Split as hardware decoders split it: marker parsing and Huffman decoding on the HOST (serial per scan; plain C, no GPU:
  * fp_jpeg_parse, fp_jpeg_entropy_decode -- run one thread per image), everything after it on the DEVICE
  * (fp_jpeg_reconstruct: dequantisation + the "islow" integer inverse DCT of jidctint.c, fancy chroma upsampling of
- * jdsample.c for 4:2:0 / 4:2:2, YCbCr -> RGB of jdcolor.c, csrc/jpeg.hip).  Accepted: SOF0 / SOF1 (sequential, 8-bit, Huffman),
- * one interleaved scan, 1 or 3 components, luma sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals.  Everything
- * else (progressive, arithmetic, 12-bit, CMYK, multi-scan): FP_ERR_UNSUPPORTED, the caller decodes those on the host.
+ * jdsample.c for 4:2:0 / 4:2:2, YCbCr -> RGB of jdcolor.c, csrc/jpeg.hip).  Accepted: SOF0 / SOF1 (sequential) and SOF2
+ * (progressive: spectral selection and successive approximation), 8-bit, Huffman, any number of scans, 1 or 3 components, luma
+ * sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals.  Everything else (arithmetic, lossless, 12-bit, CMYK, other
+ * sampling layouts): FP_ERR_UNSUPPORTED, the caller decodes those on the host.
  */
 typedef struct fp_jpeg_info {
   int32_t width, height, ncomp, restart_interval;
+  int32_t progressive, reserved;      /* 1: SOF2 (several scans build the coefficients up) */
   int32_t hs[3], vs[3];               /* sampling factors */
-  int32_t td[3], ta[3];               /* Huffman table selectors of the scan */
   int32_t mcux, mcuy;                 /* MCUs per row / column */
   int32_t blocks_w[3], blocks_h[3];   /* 8 x 8 blocks per component, padded to whole MCUs */
   int32_t comp_w[3], comp_h[3];       /* a component's true size: ceil(image * samp / max samp) */
