@@ -34,6 +34,26 @@ import time
 
 
 
+def cpu_budget():
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota.  (A gpurun box shows
+    256 cores in its affinity mask and has a quota of 16: a thread pool sized by the mask -- torch's default there is 128
+    threads -- spends its time being throttled.)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def launch_ranks(n, argv):
     """`bench.py --gpus N` without an external launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1, GPU_MAX_HW_QUEUES=8 -- see below), relay rank 0's single JSON line
@@ -46,10 +66,7 @@ def launch_ranks(n, argv):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = cpu_budget()
     procs = []
     for r in range(n):
         env = dict(os.environ)
@@ -114,6 +131,7 @@ def _requested_gpus(argv):
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
     sys.exit(launch_ranks(_requested_gpus(sys.argv[1:]), sys.argv[1:]))      # before torch / HIP are even imported
+os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))     # (read when torch's thread pools come up)
 
 # The step runs on up to four streams (detector, embedder, cross-rank exchange, RCCL's own).  HIP maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin: with the default, the embedder's stream lands on the detector's
@@ -150,12 +168,8 @@ LETTERBOX_OUT_BYTES = 256 * 256 * 3 * 4
 
 
 def host_cores():
-    """Threads for the CPU baseline: the box's CPU share (16 per GPU on the pool), never more than the affinity."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(16, n))
+    """Threads for the CPU baseline: the box's CPU share (16 per GPU on the pool), never more than the affinity / cgroup quota."""
+    return max(1, min(16, cpu_budget()))
 
 
 def cpu_baseline(det_model, emb_model, ref, frames_cpu, tau, budget_s=25.0):

@@ -40,7 +40,8 @@ def parse(data):
 def entropy_decode(data, pinned=False):
     """JPEG bytes -> (fp_jpeg_info, int16 coefficient tensor in host memory): the host half of the decode."""
     info, buf = parse(data)
-    coefs = torch.empty((int(info.n_coefs),), dtype=torch.int16, pin_memory=pinned)
+    # (page-locking a buffer costs about a millisecond: only worth it for frames, not for face crops of a few KB)
+    coefs = torch.empty((int(info.n_coefs),), dtype=torch.int16, pin_memory=pinned and info.n_coefs >= (1 << 19))
     L.check(L.load().fp_jpeg_entropy_decode(buf, len(data), C.byref(info), C.c_void_p(coefs.data_ptr())),
             "fp_jpeg_entropy_decode")
     return info, coefs

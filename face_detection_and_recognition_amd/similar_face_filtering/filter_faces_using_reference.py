@@ -34,6 +34,9 @@ def get_class_name_list(base_dir: str) -> List[str]:
     return [d.split('/')[-1] for d in sorted(glob.glob(_fix_path_for_globbing(base_dir)))]
 
 
+from ..modules.utils.jpeg import imread_batch  # noqa: E402
+
+
 def read_image_bgr(img_path: str) -> np.ndarray:
     from PIL import Image
     return np.ascontiguousarray(np.asarray(Image.open(img_path).convert("RGB"))[..., ::-1])
@@ -58,17 +61,17 @@ def preprocess_tf_standardize(frames_u8_rgb, in_size=(160, 160)):
 
 
 def read_and_preprocess_img(img_path: str, in_size=(160, 160), dct_method: str = "INTEGER_FAST", device="cuda:0"):
-    """filter_faces_using_reference.py:60-68.  The JPEG is decoded on the host (PIL; dct_method is accepted for
-    signature compatibility), everything after it runs on the device.  Returns a (h, w, 3) fp32 device tensor."""
-    import torch
-    from PIL import Image
-    img = np.asarray(Image.open(img_path).convert("RGB"))
-    t = torch.from_numpy(np.ascontiguousarray(img)).to(str(device).replace("hip", "cuda")).unsqueeze(0)
+    """filter_faces_using_reference.py:60-68.  The JPEG's Huffman stage runs on the host, the rest of the decode and everything
+    after it on the device (modules/utils/jpeg.py; libjpeg's default "islow" inverse DCT -- dct_method is accepted for
+    signature compatibility: TF's INTEGER_FAST transform has no fixture offline).  Returns a (h, w, 3) fp32 device tensor."""
+    from ..modules.utils.jpeg import imread
+    t = imread(img_path, str(device).replace("hip", "cuda"), bgr=False).unsqueeze(0)
     return preprocess_tf_standardize(t, in_size)[0]
 
 
 def embed_images(model, paths, batch_size=32, preprocess="mobile_facenet"):
-    """Decode on the host, then resize + normalise and embed on device, batch by batch.  preprocess:
+    """Decode (Huffman stage on a host thread pool, the rest on the device: modules/utils/jpeg.py), then resize + normalise and
+    embed on device, batch by batch.  preprocess:
     "mobile_facenet" = cv2-style resize of the whole image to 112x112, (x - 127.5) / 127.5, BGR
     (fde/modules/mobile_facenet/utils.py:13-17); "tf_standardize" = the reference filter's own TF preprocess
     (filter_faces_using_reference.py:60-68: RGB, [0,1], bilinear resize, per-image standardisation) at the network's
@@ -81,8 +84,9 @@ def embed_images(model, paths, batch_size=32, preprocess="mobile_facenet"):
     for i in range(0, len(paths), batch_size):
         chunk = paths[i:i + batch_size]
         plan = model.plan_for(len(chunk))
-        for j, pth in enumerate(chunk):          # images differ in size: one resize launch per image
-            img = torch.from_numpy(read_image_bgr(pth)).to(dev).unsqueeze(0)
+        decoded = imread_batch(chunk, dev)       # (B, H, W, 3) when the sizes agree, else a list
+        for j in range(len(chunk)):              # images differ in size: one resize launch per image
+            img = decoded[j].unsqueeze(0)
             if preprocess == "tf_standardize":
                 rgb = img.flip(-1).contiguous()
                 plan.input[j, ..., :3].copy_(preprocess_tf_standardize(rgb, (112, 112))[0])

@@ -1,8 +1,28 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+
+def _cpu_budget():
+    """Host cores the test process may use: the affinity mask capped by the cgroup CPU quota (a gpurun box: 256 in the mask, a
+    quota of 16 -- torch would start 128 threads and spend the oracle's CPU forwards being throttled)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))
+
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
