@@ -437,6 +437,29 @@ def run_pipeline(args):
     masks = [bytes([1 if p.kernel_name(i) == dom else 0 for i in range(p.n_ops)]) for p in plans]
     timers = [[p.new_timer() for p in plans] for _ in range(args.steps)]
 
+    def family_exclusive(name):
+        """A family's figures from the probe pass alone (each launch alone on the GPU): launches per step, average launch time,
+        compulsory bytes and reference FLOPs per launch, the roofline fraction of its own bound."""
+        ops = [(p, i) for p in plans for i in range(p.n_ops) if p.kernel_name(i) == name]
+        if not ops:
+            return None
+        us = fam_ms[name] * 1e3 / (len(ops) * N_BATCHES)
+        n_emb = pipe.emb_n_pad
+        byt = sum(p.compulsory_bytes(i, p.N if p is det_plan else n_emb) for p, i in ops) / len(ops)
+        flp = sum(p.flops(i, p.N if p is det_plan else n_emb) for p, i in ops) / len(ops)
+        bound = ops[0][0].bound(ops[0][1])
+        rec = {"kernel": name, "bound": bound, "launches_per_step": len(ops), "exclusive_avg_launch_us": round(us, 2),
+               "share_of_network_kernel_time": round(fam_ms[name] / sum(fam_ms.values()), 3)}
+        if bound == "mfma":
+            tf = flp / (us * 1e-6) / 1e12
+            rec.update({"exclusive_TFLOPs": round(tf, 1), "exclusive_frac": round(tf / X6_PEAK_TF, 4), "peak": round(X6_PEAK_TF, 1)})
+        else:
+            gb = byt / (us * 1e-6) / 1e9
+            rec.update({"exclusive_GBps": round(gb, 1), "exclusive_frac": round(gb / HBM_PEAK_GBS, 4), "peak": HBM_PEAK_GBS})
+        return rec
+    ranked = sorted(fam_ms, key=fam_ms.get, reverse=True)
+    runners_up = [family_exclusive(nm) for nm in ranked[1:4]]
+
     if not old_order and args.warmup > 0:
         run_steps(0, args.warmup)              # the W untimed warm-up steps (same form as the timed ones)
     if multi:
@@ -532,6 +555,7 @@ def run_pipeline(args):
                 "exclusive_avg_launch_us": round(excl_us, 2),
                 "exclusive_frac": round(phys_tot / max(launches, 1) / (excl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if excl_us > 0 else None,
                 "streams": 2 if args.overlap == 2 else 1,
+                "runners_up": runners_up,
                 "pipeline_GBps": round(pipe_phys / step_s / 1e9, 1),
                 "pipeline_frac": round(pipe_phys / step_s / 1e9 / HBM_PEAK_GBS, 4),
                 "pipeline_op_granular_GBps": round(pipe_alg / step_s / 1e9, 1),
