@@ -185,6 +185,35 @@ def test_embedder_split_tail_is_bit_identical(dev, two_streams):
             assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("n", [1, 511, 512, 513, 520, 607, 608, 609, 1030])
+def test_embed_split_boundaries(dev, n):
+    """FacePipeline.embed on fabricated crop items around the split's boundaries: exactly a multiple of 512 crops, one crop more
+    (a remainder padded to 8), the largest remainder that is split off (96) and one more (not split), a second multiple of 512
+    + 6; the rows equal the one-run form bit for bit and the padding crops never leak into them."""
+    from face_detection_and_recognition_amd.pipeline import FacePipeline
+    emb = W.build_embedder(dev)
+    frames = W.make_frames(4, dev, seed=77)
+    rng = np.random.default_rng(n)
+    items = np.zeros((n + 16, 9), np.int32)
+    for k in range(n + 16):
+        w, h = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+        items[k] = [k % 4, int(rng.integers(0, 1024 - w)), int(rng.integers(0, 576 - h)), w, h, 0, 0, 112, 112]
+    it = torch.from_numpy(items).to(dev)
+    outs = []
+    for split in (False, True):
+        pipe = FacePipeline(None, emb, None, split_tail=split)
+        e = pipe.embed(frames, it, n).clone()
+        torch.cuda.synchronize()
+        outs.append(e)
+        if split:
+            n_pad = (n + 7) // 8 * 8
+            main = n_pad // 512 * 512
+            did_split = main and 0 < n_pad - main <= FacePipeline.TAIL_MAX and main < n
+            assert pipe.emb_plan.n_run == (main if did_split else n_pad), (n, pipe.emb_plan.n_run, main)
+    assert outs[0].shape == (n, 512) and torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(torch.linalg.norm(outs[1], dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
 def test_filter_faces_using_reference_cli(dev, tmp_path):
     from face_detection_and_recognition_amd.similar_face_filtering import filter_faces_using_reference as F
     assert F._fix_path_for_globbing("data/") == "data/*" and F._fix_path_for_globbing("data") == "data/*"
