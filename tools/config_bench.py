@@ -132,12 +132,50 @@ def cosine(dev, M, Nr=10000, D=512):
     return rec
 
 
+def jpeg_front_end(dev, n=128, threads=None):
+    """JPEG decode of n synthetic 576 x 1024 4:2:0 frames -- host Huffman threads + device reconstruction
+    (modules/utils/jpeg.py) -- against Pillow's (libjpeg-turbo) full decode on the same host threads."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from face_detection_and_recognition_amd.modules.utils import jpeg as J
+    threads = threads or max(1, min(16, len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    rng = np.random.default_rng(0)
+    datas = []
+    for _ in range(4):
+        img = np.clip(np.cumsum(np.cumsum(rng.normal(0, 2.5, (576, 1024, 3)), 0), 1) * 0.2 + rng.normal(128, 20, (576, 1024, 3)),
+                      0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=90, subsampling=2)
+        datas.append(b.getvalue())
+    datas = [datas[i % 4] for i in range(n)]
+
+    def pil_all():
+        with ThreadPoolExecutor(threads) as pool:
+            return list(pool.map(lambda d: np.asarray(Image.open(io.BytesIO(d)).convert("RGB")), datas))
+    t_gpu = timeit(lambda: J.decode_jpeg_batch(datas, dev, threads=threads), n=2, warm=1)
+    t0 = time.perf_counter()
+    pil_all()
+    t_pil = time.perf_counter() - t0
+    info, coefs = J.entropy_decode(datas[0], pinned=True)
+    cd = coefs.to(dev)
+    out = J.reconstruct(info, cd, dev)
+    t_dev = timeit(lambda: J.reconstruct(info, cd, dev, out=out), n=50, warm=5)
+    rec = {"config": f"JPEG decode, {n} frames 576x1024 4:2:0 q90 ({sum(len(d) for d in datas) // n // 1024} KiB each), "
+                     f"{threads} host threads", "frames_per_s": round(n / t_gpu, 1), "ms": round(t_gpu * 1e3, 2),
+           "pillow_frames_per_s": round(n / t_pil, 1), "device_half_us_per_frame": round(t_dev * 1e6, 1),
+           "frac_of_roofline": None,
+           "note": "host-bound: Huffman decoding on the host threads, everything after it on the GPU; byte-identical to libjpeg-turbo"}
+    print(json.dumps(rec), file=sys.stderr, flush=True)
+    return rec
+
+
 def other_configs(dev):
     """The short legs bench.py appends to its result line (`other_configs`): BASELINE configs[2], configs[3], the embedder
     at batch 1024 and the configs[4] per-GPU shard, each with its fraction of SURVEY 8(d)'s roofline."""
     out = []
     for fn in (lambda: yolo("yolov5n", dev), lambda: yolo_to_embed(dev, cands=(4, 6), two_streams=False),
-               lambda: embed_1024(dev), lambda: cosine(dev, 125_000)):
+               lambda: embed_1024(dev), lambda: cosine(dev, 125_000), lambda: jpeg_front_end(dev)):
         out.append(fn())
         torch.cuda.empty_cache()
     return out
@@ -158,5 +196,7 @@ if __name__ == "__main__":
     if "cosine" in which:
         recs.append(cosine(dev, 125_000))
         recs.append(cosine(dev, 1_000_000))
+    if "jpeg" in which or len(sys.argv) == 1:
+        recs.append(jpeg_front_end(dev, 256))
     for r in recs:
         print(json.dumps(r), flush=True)
