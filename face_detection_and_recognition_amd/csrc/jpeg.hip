@@ -31,6 +31,9 @@ struct Huff {
   unsigned short look[512];
   int maxcode[18], valptr[17], mincode[17];
   unsigned char vals[256];
+  // sequential AC decoding: 10 bits of lookahead that hold a whole run/size code AND its value bits decode in one step:
+  // (value << 8) | (run << 4) | bits consumed, 0 = take the two-step path (the same idea as stb_image's fast_ac)
+  short fast[1024];
   bool present;
 };
 
@@ -62,6 +65,15 @@ bool build_huff(Huff& h, const unsigned char* bits /*[1..16]*/, const unsigned c
       for (int j = 0; j < (1 << (9 - lens[i])); ++j) h.look[base + j] = (unsigned short)((lens[i] << 8) | vals[i]);
     }
   }
+  for (int i = 0; i < 1024; ++i) {
+    const unsigned e = h.look[i >> 1];
+    const int len = (int)(e >> 8), run = (int)((e >> 4) & 15), sz = (int)(e & 15);
+    if (e && sz && len + sz <= 10) {
+      int v = (i >> (10 - len - sz)) & ((1 << sz) - 1);
+      if (v < (1 << (sz - 1))) v += 1 - (1 << sz);
+      if (v >= -128 && v <= 127) h.fast[i] = (short)((v * 256) | (run << 4) | (len + sz));
+    }
+  }
   h.present = true;
   return true;
 }
@@ -74,6 +86,19 @@ struct BitReader {
   int marker;               // a marker met in the entropy-coded data (0 = none): the reader feeds zeros behind it
   void init(const unsigned char* b, const unsigned char* e) { p = b, end = e, acc = 0, nbits = 0, marker = 0; }
   void fill() {
+    if (!marker && end - p >= 8) {             // eight bytes ahead with no 0xff among them: take the whole bytes that fit at once
+      unsigned long long w;
+      __builtin_memcpy(&w, p, 8);
+      if (!((~w - 0x0101010101010101ull) & w & 0x8080808080808080ull)) {
+        const int k = (64 - nbits) >> 3;
+        if (k > 0) {
+          w = __builtin_bswap64(w);
+          acc |= (w >> nbits) & (~0ull << (64 - nbits - 8 * k));
+          p += k, nbits += 8 * k;
+        }
+        return;
+      }
+    }
     while (nbits <= 56) {
       unsigned v = 0;
       if (!marker && p < end) {
@@ -121,6 +146,38 @@ inline int huff_decode(BitReader& br, const Huff& h) {
 }
 
 inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+// One block of a sequential scan (jdhuff.c decode_mcu): DC difference, then run / size pairs up to EOB.
+inline int decode_block_seq(BitReader& br, const Huff& hd, const Huff& ha, int& pred, int16_t* blk) {
+  int s = huff_decode(br, hd);
+  if (s < 0 || s > 11) return FP_ERR_INVALID_ARG;
+  if (s) pred += extend(br.get(s), s);
+  blk[0] = (int16_t)pred;
+  for (int k = 1; k < 64;) {
+    if (br.nbits < 32) br.fill();                  // a code (<= 16 bits) and its value bits (<= 11) are in the accumulator
+    const int fe = ha.fast[br.peek(10)];
+    if (fe) {
+      k += (fe >> 4) & 15;
+      if (k > 63) return FP_ERR_INVALID_ARG;
+      blk[kZigzag[k++]] = (int16_t)(fe >> 8);
+      br.skip(fe & 15);
+      continue;
+    }
+    const int rs = huff_decode(br, ha);
+    if (rs < 0) return FP_ERR_INVALID_ARG;
+    const int r = rs >> 4;
+    s = rs & 15;
+    if (s == 0) {
+      if (r != 15) break;                          // EOB
+      k += 16;
+      continue;
+    }
+    k += r;
+    if (k > 63) return FP_ERR_INVALID_ARG;
+    blk[kZigzag[k++]] = (int16_t)extend(br.get(s), s);
+  }
+  return FP_OK;
+}
 
 inline unsigned be16(const unsigned char* p) { return ((unsigned)p[0] << 8) | p[1]; }
 
@@ -312,27 +369,8 @@ int decode_scan(BitReader& br, const fp_jpeg_info& info, const Scan& sc, const H
           for (int hh = 0; hh < nh; ++hh) {
             int16_t* blk = coefs + info.coef_off[c] + ((long)(my * nv + v) * info.blocks_w[c] + (mx * nh + hh)) * 64;
             if (!info.progressive) {
-              // ---- sequential: DC difference, then run / size pairs up to EOB ----
-              int s = huff_decode(br, dc[sc.td[i]]);
-              if (s < 0 || s > 11) return FP_ERR_INVALID_ARG;
-              if (s) pred[c] += extend(br.get(s), s);
-              blk[0] = (int16_t)pred[c];
-              const Huff& ha = ac[sc.ta[i]];
-              for (int k = 1; k < 64;) {
-                const int rs = huff_decode(br, ha);
-                if (rs < 0) return FP_ERR_INVALID_ARG;
-                const int r = rs >> 4;
-                s = rs & 15;
-                if (s == 0) {
-                  if (r != 15) break;            // EOB
-                  k += 16;
-                  continue;
-                }
-                k += r;
-                if (k > 63) return FP_ERR_INVALID_ARG;
-                blk[kZigzag[k]] = (int16_t)extend(br.get(s), s);
-                ++k;
-              }
+              const int rc = decode_block_seq(br, dc[sc.td[i]], ac[sc.ta[i]], pred[c], blk);
+              if (rc) return rc;
             } else if (sc.Ss == 0) {
               if (sc.Ah == 0) {                    // ---- DC first scan ----
                 const int s = huff_decode(br, dc[sc.td[i]]);

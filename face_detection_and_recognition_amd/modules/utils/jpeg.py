@@ -74,8 +74,9 @@ def decode_jpeg_batch(datas, device, bgr=True, threads=8):
     if device.type != "cuda":
         raise L.FacepathError("decode_jpeg_batch reconstructs on a HIP device; there is no CPU path")
     with ThreadPoolExecutor(max_workers=max(1, min(threads, len(datas)))) as pool:
-        host = list(pool.map(lambda d: entropy_decode(d, pinned=True), datas))
-    return [reconstruct(info, coefs.to(device, non_blocking=True), device, bgr) for info, coefs in host]
+        # in order, as each frame's Huffman decode finishes: its copy and reconstruction run under the decodes still going
+        return [reconstruct(info, coefs.to(device, non_blocking=True), device, bgr)
+                for info, coefs in pool.map(lambda d: entropy_decode(d, pinned=True), datas)]
 
 
 def imread(path, device, bgr=True):
@@ -113,9 +114,8 @@ def imread_batch(paths, device, bgr=True, threads=8):
                 pass
         return None
     with ThreadPoolExecutor(max_workers=max(1, min(threads, len(datas)))) as pool:
-        hosts = list(pool.map(host, datas))
-    frames = [reconstruct(h[0], h[1].to(device, non_blocking=True), device, bgr) if h is not None else imread(p, device, bgr)
-              for h, p in zip(hosts, paths)]
+        frames = [reconstruct(h[0], h[1].to(device, non_blocking=True), device, bgr) if h is not None else imread(p, device, bgr)
+                  for h, p in zip(pool.map(host, datas), paths)]
     if frames and all(f.shape == frames[0].shape for f in frames):
         return torch.stack(frames)
     return frames
