@@ -109,6 +109,31 @@ def test_jpeg_refusals_and_damaged_input(lib):
         assert _host_decode(lib, src[:len(src) // 3])[0] in (0, -1)
 
 
+def test_jpeg_host_half_mutation_fuzz_under_asan_ubsan(tmp_path):
+    """The parser and Huffman decoder read bytes nobody vetted: tools/fuzz/run_jpeg_fuzz.sh builds the host half of csrc/jpeg.hip
+    with AddressSanitizer + UndefinedBehaviorSanitizer (CPU only, no device code) and feeds it truncated / bit-flipped / 0xff- and
+    zero-stuffed variants of 50 small files (4:4:4 / 4:2:2 / 4:2:0 / gray, restart intervals, progressive), each input in an
+    exact-size heap block: any read or write outside it, any shift or overflow the language leaves undefined, aborts the run.
+    (1.5 M inputs of the same campaign ran clean when the decoder was written; this is the 40 k regression slice.)"""
+    import shutil
+    import subprocess
+    if not (os.path.exists("/opt/rocm/bin/hipcc") and os.path.exists("/opt/rocm/lib/llvm/bin/clang++") and shutil.which("nm")):
+        pytest.skip("needs hipcc + clang++ + nm")
+    env = dict(os.environ, FUZZ_BUILD_DIR=str(tmp_path))
+    for attempt in range(2):
+        r = subprocess.run([os.path.join(ROOT, "tools", "fuzz", "run_jpeg_fuzz.sh"), "800", "3"], capture_output=True, text=True,
+                           timeout=600, env=env)
+        report = "Sanitizer" in r.stderr or "runtime error" in r.stderr
+        if r.returncode == 0 or report:
+            break
+    if r.returncode != 0 and not report:
+        pytest.skip("the sanitizer build of the fuzzer did not come up here: " + r.stderr[-300:])
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    words = r.stdout.strip().splitlines()[-1].split()
+    n, ok, refused = int(words[0]), int(words[2]), int(words[4])
+    assert n >= 39_000 and ok > n // 10 and refused > n // 10, r.stdout      # both outcomes are exercised
+
+
 @pytest.mark.gpu
 def test_jpeg_device_reconstruction_is_byte_identical_to_libjpeg_turbo(dev, lib):
     """decode_jpeg (host Huffman -> device dequantise + islow IDCT + fancy upsampling + YCbCr -> RGB) == Pillow's decode, byte
