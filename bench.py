@@ -77,6 +77,10 @@ def launch_ranks(n, argv):
         env.setdefault("OMP_NUM_THREADS", str(max(1, cores // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    import threading
+    chunks = []                               # rank 0's stdout is drained while it runs (a full pipe would block it)
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "1500"))
     failed = None
     while failed is None and any(p.poll() is None for p in procs):
@@ -100,11 +104,12 @@ def launch_ranks(n, argv):
                 time.sleep(0.05)
             if p.poll() is None:
                 p.kill()
-        procs[0].stdout.close()
+        reader.join(timeout=5)
         sys.stderr.write(f"bench.py launcher: rank {failed[0]} failed (exit code {failed[1]}); all ranks stopped\n"
                          if failed[0] >= 0 else "bench.py launcher: timed out; all ranks stopped\n")
         return failed[1] if 0 < failed[1] < 256 else 1
-    out = procs[0].stdout.read().decode()
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode()
     lines = [ln for ln in out.splitlines() if ln.strip()]
     try:
         rec = json.loads(lines[-1])
