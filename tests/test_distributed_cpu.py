@@ -155,6 +155,93 @@ def test_sharded_similarity_world2_gloo():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _worker_n(rank, world, port, q):
+    """The same data path at any world size: every rank holds a ragged share, the expected matches are computed from ALL
+    ranks' rows with numpy (each rank can regenerate them: same seed)."""
+    sys.path.insert(0, ROOT)
+    from face_detection_and_recognition_amd import distributed as D
+    from oracle import similarity_ref
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    G = rng.normal(0, 1, (203, 32)).astype(np.float32)
+    R = rng.normal(0, 1, (world * 9 + 5, 32)).astype(np.float32)
+    g0, g1 = D.shard_range(len(G), rank, world)
+    r0, r1 = D.shard_range(len(R), rank, world)
+
+    def filter_fn(g, r, tau):
+        b, a, k, _ = similarity_ref.cosine_filter(g.numpy(), r.numpy(), tau)
+        return torch.from_numpy(b), torch.from_numpy(a), torch.from_numpy(k)
+
+    best, arg, keep = D.sharded_cosine_filter(torch.from_numpy(G[g0:g1]), torch.from_numpy(R[r0:r1]), 0.2, filter_fn)
+    rb, ra, rk, _ = similarity_ref.cosine_filter(G, R, 0.2)
+    ok = np.allclose(best.numpy(), rb[g0:g1], atol=1e-6) and np.array_equal(arg.numpy(), ra[g0:g1]) and \
+        np.array_equal(keep.numpy(), rk[g0:g1])
+    rows, offs = D.all_gather_rows(torch.from_numpy(R[r0:r1]))
+    ok = ok and np.array_equal(rows.numpy(), R) and list(offs) == [D.shard_range(len(R), i, world)[0] for i in range(world)] + [len(R)]
+
+    def filter_rinv(g, r, tau, rinv):
+        gn = g.numpy() / np.maximum(np.linalg.norm(g.numpy(), axis=1, keepdims=True), 1e-30)
+        sc = gn @ (r.numpy() * rinv.numpy()[:, None]).T
+        return torch.from_numpy(sc.max(1)), torch.from_numpy(sc.argmax(1).astype(np.int32)), torch.from_numpy(sc.max(1) >= tau)
+
+    def inv_norm(r):
+        return 1.0 / torch.linalg.norm(r, dim=1).clamp_min(1e-30)
+
+    cap, D_ = 16, 32
+    ex = D.StepExchange(cap, D_, "cpu", 0.1, filter_rinv, inv_norm)
+    outs, want = [], []
+    for k in range(3):
+        counts = [(3 + 5 * i + 2 * k) % 14 for i in range(world)]          # ragged, some ranks empty in some steps
+        embs = [rng.normal(0, 1, (n, D_)).astype(np.float32) for n in counts]
+        mine = embs[rank]
+        others = [(i, embs[i]) for i in range(world) if i != rank and counts[i]]
+        if counts[rank] and others:
+            mn = mine / np.linalg.norm(mine, axis=1, keepdims=True)
+            sc = np.concatenate([mn @ (e / np.linalg.norm(e, axis=1, keepdims=True)).T for _, e in others], 1)
+            col_rank = np.concatenate([np.full(len(e), i) for i, e in others])
+            col_row = np.concatenate([np.arange(len(e)) for _, e in others])
+            j = sc.argmax(1)
+            want.append((counts, sc.max(1), col_rank[j] * cap + col_row[j]))
+        else:
+            want.append((counts, None, None))
+        got = ex.submit(torch.from_numpy(mine), counts[rank])
+        if got is not None:
+            outs.append(got)
+    outs.append(ex.drain())
+    for (counts, wbest, warg), (gb, ga, gk, gc, gcap) in zip(want, outs):
+        n = counts[rank]
+        ok = ok and gc.tolist() == counts and gcap == cap
+        if wbest is not None:
+            pos = wbest > 0        # a row whose best cross-rank cosine is negative lands on a masked column: arg -1
+            ok = ok and np.allclose(gb.numpy()[:n][pos], wbest[pos], atol=1e-5) and np.array_equal(ga.numpy()[:n][pos], warg[pos])
+            ok = ok and (ga.numpy()[:n][~pos] == -1).all()
+            ok = ok and np.array_equal(gk.numpy()[:n], wbest >= 0.1)
+        elif n:
+            ok = ok and (ga.numpy()[:n] == -1).all() and not gk.numpy()[:n].any()
+    mean = D.sharded_l2_mean(torch.from_numpy(R[r0:r1]))
+    ok = ok and np.allclose(mean.numpy(), R.mean(0), atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_similarity_and_step_exchange_world_n_gloo(world):
+    """The exchange at the driver's scaling sizes (4 and 8 ranks, gloo on the CPU): arg = rank * cap + row across several
+    peers, own rows masked, ranks with no face in a step, the one-step-late hand-out."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
 def _run_bench(extra_env, *argv):
     import subprocess
     env = dict(os.environ)
