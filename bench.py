@@ -260,6 +260,8 @@ def init_dist():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if os.environ.get("BENCH_MAIN_PRIO"):      # lab (tools/lab/stream_prio_ab.sh): the detector's stream at another priority
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["BENCH_MAIN_PRIO"])))
     return world, rank, dev, dist, backend
 
 

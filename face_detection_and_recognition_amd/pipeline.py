@@ -6,6 +6,8 @@ similarity filter, run for a whole batch of frames at once: every stage is a HIP
 caller's stream and the only host round trip is reading the number of faces found (it sizes the embedder batch).
 """
 import numpy as np
+import os
+
 import torch
 
 from . import _lib as L
@@ -47,7 +49,8 @@ class FacePipeline:
         # step_overlapped with two_streams: embed + filter of batch k run on a SIDE stream beside the detector of batch
         # k + 1 (the split-MFMA embedder kernels are matrix-core bound, the BlazeFace kernels vector-ALU / HBM bound, and
         # every kernel's last, partly empty round of workgroups is filled by the other stream's work)
-        self.emb_stream = torch.cuda.Stream(device=self.dev) if two_streams else None
+        prio = int(os.environ.get("FP_EMB_STREAM_PRIO", "0"))     # lab knob (tools/lab/README.md): -1 = high priority
+        self.emb_stream = torch.cuda.Stream(device=self.dev, priority=prio) if two_streams else None
         self.split_tail = bool(split_tail)
         self.tail_stream = torch.cuda.Stream(device=self.dev) if split_tail else None
         net = getattr(detector, "net", None)
