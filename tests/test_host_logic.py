@@ -43,6 +43,52 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.FpResizeItem) == 36
 
 
+def test_header_is_plain_c_and_a_c_caller_agrees_with_the_python_mirror(lib, tmp_path):
+    """The boundary is a C ABI: include/facepath.h compiles as C99 (-pedantic, no C++ in it), a C program links against
+    libfacepath.so and drives the GPU-free entry points (fp_abi_version, the JPEG host half on a fixture), and the struct
+    layouts the C compiler derives from the header -- sizes and the offset of every field -- are the ones _lib.py's ctypes
+    mirrors use."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    mirrors = {"fp_op": L.FpOp, "fp_ext": L.FpExt, "fp_resize_item": L.FpResizeItem, "fp_jpeg_info": L.FpJpegInfo}
+    prints = []
+    for cname, cls in mirrors.items():
+        prints.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            prints.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "caller.c"
+    template = open(os.path.join(ROOT, "tests", "data", "c_caller.c.in")).read()
+    src.write_text(template.replace("/*LAYOUT_PRINTS*/", "\n  ".join(prints)))
+    libdir = os.path.dirname(L.LIB_PATH)
+    exe = tmp_path / "caller"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                        "-L", libdir, "-lfacepath", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    fixture = os.path.join(ROOT, "tests", "golden", "jpeg", "ref_test2_faces_3.jpg")
+    r = subprocess.run([str(exe), fixture], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    got = dict(ln.rsplit(" ", 1) for ln in r.stdout.splitlines() if ln.startswith("fp_"))
+    for cname, cls in mirrors.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if not ln.startswith("fp_")}
+    assert int(lines["abi"][0]) == L.ABI_VERSION
+    # the same file through the Python binding: same geometry, same coefficients
+    data = open(fixture, "rb").read()
+    info = L.FpJpegInfo()
+    buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
+    assert lib.fp_jpeg_parse(buf, len(data), ctypes.byref(info)) == 0
+    coefs = np.zeros(int(info.n_coefs), np.int16)
+    assert lib.fp_jpeg_entropy_decode(buf, len(data), ctypes.byref(info), coefs.ctypes.data_as(ctypes.c_void_p)) == 0
+    want_sum = int((coefs.astype(np.int64) * (np.arange(len(coefs)) % 7 + 1)).sum())
+    assert [int(v) for v in lines["jpeg"][:5]] == [info.width, info.height, info.ncomp, int(info.n_coefs), want_sum]
+    assert lines["jpeg"][5:] == ["rc", "0"] and lines["err"] == ["-1", "-1"]
+
+
 def test_plans_validate_and_reject_bad_offsets(lib):
     for net in (BlazeFace(True), BlazeFace(False), MobileFaceNet(512)):
         pb = net._emit(3)[0]
