@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void blazepair_kernel(BlazePairArgs p) {
 template <int W>
 int launch_pair(const BlazePairArgs& a, hipStream_t s) {
   constexpr int C = 24, NSUB = 4 / (W / 32);
-  const size_t lds = 4 * ((size_t)2 * 10 * C + 64 + (size_t)NSUB * 4 * (W + 2) * C + 4 * (size_t)32 * (C + 4));
+  size_t lds = 4 * ((size_t)2 * 10 * C + 64 + (size_t)NSUB * 4 * (W + 2) * C + 4 * (size_t)32 * (C + 4));
+  if ((size_t)fp_get_knobs().pair_lds_min > lds) lds = (size_t)fp_get_knobs().pair_lds_min;      // lab knob, 0 in the product
   const hipError_t ae = hipFuncSetAttribute((const void*)blazepair_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);

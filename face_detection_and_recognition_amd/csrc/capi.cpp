@@ -25,6 +25,8 @@ static fp_knobs read_knobs() {
   k.x6_quarter14 = env_int("FP_X6_QUARTER14");
   k.x6_spec14 = env_int("FP_X6_SPEC14");
   k.pwx6_small_maxk = env_int("FP_PWX6_SMALL_MAXK");
+  k.pair_lds_min = env_int("FP_PAIR_LDS_MIN");
+  k.x6_lds_min = env_int("FP_X6_LDS_MIN");
   return k;
 }
 static fp_knobs g_knobs = read_knobs();

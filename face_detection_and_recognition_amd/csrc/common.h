@@ -33,6 +33,8 @@ struct fp_knobs {
   int x6_quarter14;      // FP_X6_QUARTER14: 14 x 14 Depth_Wise blocks as 7 x 7 tiles (lab)
   int x6_spec14;         // FP_X6_SPEC14: the wave-specialised 14 x 14 form (lab)
   int pwx6_small_maxk;   // FP_PWX6_SMALL_MAXK: K at or below which pwx6 takes its small tiles (lab)
+  int pair_lds_min;      // FP_PAIR_LDS_MIN: blazepair kernels request at least this much LDS (lab: > 80 KiB = one workgroup per CU)
+  int x6_lds_min;        // FP_X6_LDS_MIN: the same for the dwblock_x6 / x6d kernels (lab)
 };
 const fp_knobs& fp_get_knobs();
 

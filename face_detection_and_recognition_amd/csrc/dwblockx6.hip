@@ -386,13 +386,14 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
 template <int C, int HW>
 int launch_x6(const DwbX6Args& a, hipStream_t s) {
   using K = X6Cfg<C, HW>;
+  const int lds_bytes = fp_get_knobs().x6_lds_min > K::LDS_BYTES ? fp_get_knobs().x6_lds_min : K::LDS_BYTES;   // lab knob, 0 in the product
   const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6_kernel<C, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            K::LDS_BYTES);
+                                            lds_bytes);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
     return FP_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((dwblock_x6_kernel<C, HW>), dim3(a.N * K::NBAND), dim3(256), K::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dwblock_x6_kernel<C, HW>), dim3(a.N * K::NBAND), dim3(256), lds_bytes, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
@@ -1289,13 +1290,14 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
 template <int CI, int G_, int CO, int HW, bool DWIN = false>
 int launch_x6d(const DwbX6Args& a, hipStream_t s) {
   using K = X6DCfg<CI, G_, CO, HW>;
+  const int lds_bytes = fp_get_knobs().x6_lds_min > K::LDS_BYTES ? fp_get_knobs().x6_lds_min : K::LDS_BYTES;   // lab knob, 0 in the product
   const hipError_t ae = hipFuncSetAttribute((const void*)dwblock_x6d_kernel<CI, G_, CO, HW, DWIN>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
     return FP_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((dwblock_x6d_kernel<CI, G_, CO, HW, DWIN>), dim3(a.N * K::NBAND), dim3(256), K::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dwblock_x6d_kernel<CI, G_, CO, HW, DWIN>), dim3(a.N * K::NBAND), dim3(256), lds_bytes, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
