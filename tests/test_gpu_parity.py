@@ -470,6 +470,35 @@ def test_blazeface_decode_vs_reference_golden(dev, lib):
         np.testing.assert_allclose(got[:, 16], d[:, 16], rtol=0, atol=2e-7)
 
 
+def test_blazeface_decode_extreme_scores_and_threshold_edge(dev, lib):
+    """Raw scores far outside the clip range, infinities, NaN and values whose sigmoid sits next to min_score: the candidate set
+    is the oracle's (blazeface.py:321-371: clamp to +-100, sigmoid, `>= min_score`; a NaN score is not a candidate), rows
+    decoded exactly, scores 2e-7."""
+    g = golden("blazeface_decode")
+    A = g["raw_box"].shape[1]
+    rng = np.random.default_rng(3)
+    B = 3
+    rb = np.tile(g["raw_box"][:1], (B, 1, 1)).astype(np.float32)
+    edge = np.float32(np.log(0.65 / 0.35))                                  # sigmoid(edge) ~ 0.65
+    pool = np.array([-1e30, -1000, -100.5, -100, -1, 0, 1, 100, 100.5, 1000, 1e30, np.inf, -np.inf, np.nan,
+                     edge, np.nextafter(edge, np.float32(9)), np.nextafter(edge, np.float32(-9)), edge + 1e-6, edge - 1e-6],
+                    np.float32)
+    rs = pool[rng.integers(0, len(pool), (B, A, 1))]
+    rbt, rst, an = (torch.from_numpy(a).to(dev) for a in (rb, rs, g["anchors"]))
+    cand = torch.zeros((B, A, 17), device=dev)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    L.check(lib.fp_blaze_decode(L.ptr(rbt), L.ptr(rst), L.ptr(an), B, A, 256.0, 256.0, 256.0, 256.0, 100.0, 0.65,
+                                L.ptr(cand), L.ptr(cnt), None), "decode")
+    torch.cuda.synchronize()
+    ref = blazeface_ref.tensors_to_detections(torch.from_numpy(rb), torch.from_numpy(rs), torch.from_numpy(g["anchors"]), 256.0)
+    assert cnt.cpu().numpy().tolist() == [len(d) for d in ref]
+    for i, d in enumerate(ref):
+        got = cand[i, :len(d)].cpu().numpy()
+        assert np.isfinite(got).all()
+        np.testing.assert_array_equal(got[:, :16], d.numpy()[:, :16])
+        np.testing.assert_allclose(got[:, 16], d.numpy()[:, 16], rtol=0, atol=2e-7)
+
+
 def _wnms_gpu(dev, lib, dets_list, thr=0.3):
     B = len(dets_list)
     nmax = 896
