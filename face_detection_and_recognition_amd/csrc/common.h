@@ -120,6 +120,9 @@ bool fp_dwblock_x6_supported(const fp_op& op);   // DWBLOCK with FP_OPF_SPLIT3: 
 long fp_dwblock_x6_we_floats(const fp_op& op);   // floats behind w_off / slope_off of such an op
 long fp_dwblock_x6_wp_floats(const fp_op& op);
 int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_shufdown_supported(const fp_op& op);     // FP_OP_SHUFDOWN: a whole stride-2 ShuffleV2Block (shufdown.hip)
+long fp_shufdown_w_floats(const fp_op& op);
+int fp_launch_shufdown(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pwx6_eligible(const fp_op& op);     // CONV with FP_OPF_SPLIT3: pointwise conv on the bf16x6 split-MFMA kernel (pwx6.hip)
 long fp_pwx6_w_floats(const fp_op& op);
 int fp_pwx6_mt(const fp_op& op);

@@ -262,6 +262,7 @@ class ShuffleV2Block(_NoCompute):
                                      ConvParams(bf, bf, 1, 1, 0, bias=False), BNParams(bf, eps=1e-3), _Tag())
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pairs (A/B parity tests)
+    FUSE_DOWN = True   # the whole stride-2 block as one FP_OP_SHUFDOWN where csrc/shufdown.hip has the shape (32 -> 128 channels)
 
     def emit(self, pb, x, out=None):
         """out: optional View (C = oup) the block writes into, e.g. a channel slice of a later Concat's buffer."""
@@ -273,6 +274,12 @@ class ShuffleV2Block(_NoCompute):
         # cat + channel_shuffle(2) is the last conv's epilogue (FP_RES_SHUFFLE2): out[2n] = other half, out[2n+1] = conv
         b2 = self.branch2
         fuse2 = ShuffleV2Block.FUSE and self.bf % 64 == 0 and self.bf <= 128     # dw3x3 + 1x1 of branch2 in one kernel
+        if s == 2 and ShuffleV2Block.FUSE and ShuffleV2Block.FUSE_DOWN and pb.shufdown_supported(x, View(ob, oc, self.oup), self.inp, self.bf):
+            b1 = self.branch1
+            pb.shufdown(x, npy(b1[0].weight), _bn_sb(b1[1]), npy(b1[2].weight), _bn_sb(b1[3]),
+                        npy(b2[0].weight), _bn_sb(b2[1]), npy(b2[3].weight), _bn_sb(b2[4]), npy(b2[5].weight), _bn_sb(b2[6]),
+                        View(ob, oc, self.oup))
+            return out
         if s == 1:
             first = View(x.buf, x.coff, self.bf)                                          # x1 passthrough
             x2 = View(x.buf, x.coff + self.bf, self.bf)

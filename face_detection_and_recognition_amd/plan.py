@@ -736,6 +736,56 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (extra + pix * (cin + cmid) + (pix + opix) * cmid + opix * (cmid + cout)))
         return out
 
+    # shapes csrc/shufdown.hip is instantiated for: (Cin, branch width)
+    SHUFDOWN_SHAPES = ((32, 64),)
+
+    @classmethod
+    def shufdown_supported(cls, x, out, cin, cb):
+        """Mirror of fp_shufdown_supported (csrc/shufdown.hip): a whole stride-2 ShuffleV2Block as one op."""
+        if not cls.X6 or (cin, cb) not in cls.SHUFDOWN_SHAPES or x.C != cin or out.C != 2 * cb or out.cmul != 1:
+            return False
+        if x.H % 2 or x.W % 2 or (out.H, out.W) != (x.H // 2, x.W // 2) or x.buf.rowpad or out.buf.rowpad:
+            return False
+        for v in (x, out):
+            if v.buf.ld % 4 or (v.buf.off + v.coff) % 4 or v.buf.ns % 4 or v.buf.ns < v.H * v.W * v.buf.ld:
+                return False
+        return True
+
+    def shufdown(self, x, b1_dw, b1_dw_aff, b1_pw, b1_pw_aff, pw1, pw1_aff, dw2, dw2_aff, pw2, pw2_aff, out):
+        """A whole stride-2 ShuffleV2Block (y5/models/common.py:127-176) as ONE op (FP_OP_SHUFDOWN, csrc/shufdown.hip):
+        branch1 = dw3x3 s2 + BN -> 1x1 + BN + SiLU, branch2 = 1x1 + BN + SiLU -> dw3x3 s2 + BN -> 1x1 + BN + SiLU,
+        out[2c] = branch1[c], out[2c + 1] = branch2[c].  *_aff = (scale, bias) of the eval-mode BatchNorm.  The parameter block's
+        layout is facepath.h "SHUFDOWN"."""
+        cin, cb = x.C, pw1.shape[0]
+        assert self.shufdown_supported(x, out, cin, cb)
+        assert b1_dw.shape == (cin, 1, 3, 3) and b1_pw.shape[:2] == (cb, cin) and pw1.shape[:2] == (cb, cin)
+        assert dw2.shape == (cb, 1, 3, 3) and pw2.shape[:2] == (cb, cb)
+        op = self._base(L.OP_SHUFDOWN, x, out, out.H, out.W)
+        op.Cout, op.Cmid = 2 * cb, cb
+        op.KH = op.KW = 3
+        op.stride = 2
+        op.pad_t = op.pad_l = 1
+        op.act = op.act2 = L.ACT_SILU
+        op.flags |= L.OPF_SPLIT3
+        ks, r = cin // 32, cb // 32
+
+        def planes(a):
+            return np.ascontiguousarray(a).reshape(-1).view(np.float32)
+        w_b1 = split3_bf16(np.asarray(b1_pw, np.float32).reshape(cb, cin)).reshape(3, cb, ks, 32).transpose(2, 0, 1, 3)   # [ks][3][co][k']
+        w_1 = split3_bf16(np.asarray(pw1, np.float32).reshape(cb, cin)).reshape(3, r, 32, ks, 32).transpose(1, 0, 3, 2, 4)  # [r][3][ks][g'][k']
+        w_2 = split3_bf16(np.asarray(pw2, np.float32).reshape(cb, cb)).reshape(3, cb, r, 32).transpose(2, 0, 1, 3)           # [r][3][co][g']
+        blob = [pack_dw_weight(b1_dw, cin), pad_vec(b1_dw_aff[0], cin), pad_vec(b1_dw_aff[1], cin),
+                planes(w_b1), pad_vec(b1_pw_aff[0], cb), pad_vec(b1_pw_aff[1], cb),
+                planes(w_1), pad_vec(pw1_aff[0], cb), pad_vec(pw1_aff[1], cb),
+                pack_dw_weight(dw2, cb), pad_vec(dw2_aff[0], cb), pad_vec(dw2_aff[1], cb),
+                planes(w_2), pad_vec(pw2_aff[0], cb), pad_vec(pw2_aff[1], cb)]
+        op.w_off = self.add_weight(np.concatenate(blob))
+        self.ops.append(op)
+        pix, opix = x.H * x.W, out.H * out.W
+        # SURVEY 8(d): the five convs of the block, each input once + output once
+        self.alg_bytes.append(4 * self.N * ((pix + opix) * cin + opix * (cin + cb) + pix * (cin + cb) + (pix + opix) * cb + opix * 2 * cb))
+        return out
+
     def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
         """First conv of a network reading u8 frames itself (FP_OP_STEM_U8): KxK (3 or 5) stride 2, Cout <= 64, dense
         output buffer.  u8 = (H, W, frame_h, frame_w, ext_index): the H x W letterbox canvas is resampled from the
@@ -1033,7 +1083,7 @@ class CompiledPlan:
             if op.flags & L.OPF_IN_UP2:                          # the leading res_C channels come from the half-size map
                 b_in = op.H * op.W * (op.Cin - op.res_C) * 4 + op.res_H * op.res_W * op.res_C * 4
         cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_BLAZECHAIN, L.OP_YSTEM, L.OP_YSTEM_U8,
-                                L.OP_STEM_U8) else op.Cin
+                                L.OP_STEM_U8, L.OP_SHUFDOWN) else op.Cin
         oh, ow = (op.H, op.W) if k in (L.OP_COPY, L.OP_L2NORM) else (op.OH, op.OW)
         b_out = oh * ow * cout * 4 * (2 if op.res_mode == L.RES_SHUFFLE2 else 1)
         b_res = 0
@@ -1065,6 +1115,8 @@ class CompiledPlan:
             f = op.Cmid * opix * (9 * op.Cin + op.Cin * op.Cout)
         elif k == L.OP_DWBLOCK:
             f = op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cout)
+        elif k == L.OP_SHUFDOWN:   # branch1: dw + 1x1; branch2: 1x1 at full resolution, dw, 1x1
+            f = opix * (9 * op.Cin + op.Cin * op.Cmid) + op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cmid)
         else:
             f = 0
         return 2.0 * n * f

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 9
+#define FP_ABI_VERSION 10
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -82,9 +82,12 @@ enum fp_op_kind {
                            the stride-2 block that ends the stage (24 -> 24 / 48, half-size output); see "BLAZEPAIR" */
   FP_OP_BLAZECHAIN = 14, /* a RUN of fp_op.Cmid consecutive stride-1 96 -> 96 BlazeBlocks on the 16 x 16 map (blazeface.py:12-47,
                            146-152) in one kernel: one image per workgroup stays in LDS for the whole run.  See "BLAZECHAIN" */
-  FP_OP_DWBLOCK = 12    /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
+  FP_OP_DWBLOCK = 12,   /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
                            dw3x3 stride 1 (+BN, PReLU) -> 1x1 project (+BN) [+ x]; the expanded tensor (Cmid channels)
                            lives in LDS only.  Shapes: see "DWBLOCK" below; anything else fails validation */
+  FP_OP_SHUFDOWN = 15   /* ABI 10.  a WHOLE stride-2 ShuffleV2Block (y5/models/common.py:127-176) in one kernel: branch1 = dw3x3 s2 + BN
+                           -> 1x1 + BN + SiLU, branch2 = 1x1 + BN + SiLU -> dw3x3 s2 + BN -> 1x1 + BN + SiLU, cat + channel_shuffle(2)
+                           as the store pattern; nothing but x and the shuffled output touches HBM.  See "SHUFDOWN" */
 };
 
 enum fp_act { FP_ACT_NONE = 0, FP_ACT_RELU = 1, FP_ACT_PRELU = 2, FP_ACT_SILU = 3 };
@@ -261,8 +264,18 @@ typedef struct fp_op {
  *            flags = FP_OPF_SPLIT3: the 1x1 convs run as bf16x6 split MFMAs.  w_off -> Cmid blocks back to back, each
  *            [1280 floats: [9][96] depthwise taps (ky*3 + kx), [96] depthwise bias, [96] 1x1 bias, 224 pad] followed by
  *            three slabs (k = 32 s .. 32 s + 31) of [3 planes][96 output channels][32 k] bf16 (13 824 floats).
+ *   SHUFDOWN : in = x (H x W even, Cin = 32 channels), out = the block's output (OH x OW = H/2 x W/2, Cout = 128 = 2 * Cmid dense
+ *            channels at out_off, out_ld >= 128), Cmid = 64 (the width of a branch), 3x3 stride 2 pad 1, act = act2 = FP_ACT_SILU,
+ *            flags = FP_OPF_SPLIT3 (all three 1x1 convs run as bf16x6 split MFMAs).  One parameter block at w_off (floats; a weight
+ *            plane holds two bf16 per float, planes in the order h, m, l of plan.py split3_bf16):
+ *              [9][32] branch1 depthwise taps (ky*3 + kx), [32] BN scale, [32] BN bias;
+ *              [3 planes][64 co][32 k] branch1 1x1;  [64] BN scale, [64] BN bias;
+ *              [2 rounds][3 planes][32 g][32 k] branch2 first 1x1 (round r = output channels 32 r .. 32 r + 31);  [64] scale, [64] bias;
+ *              [9][64] branch2 depthwise taps, [64] BN scale, [64] BN bias;
+ *              [2 rounds][3 planes][64 co][32 g] branch2 second 1x1 (round r = input channels 32 r ..);  [64] scale, [64] bias.
+ *            out[2 c] = branch1[c], out[2 c + 1] = branch2[c].
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env; 10 = FP_OP_SHUFDOWN.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

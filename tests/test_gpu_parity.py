@@ -1697,6 +1697,37 @@ def test_yolo_shufflev2_fused_branches_at_stage_shapes(dev):
         assert rel_err(got[:, :want.shape[1]], want) < 1e-5
 
 
+@pytest.mark.parametrize("hw,n", [((22, 26), 3), ((64, 96), 2), ((2, 2), 1), ((160, 160), 5), ((10, 34), 4)])
+def test_yolo_shufflev2_stride2_block_in_one_kernel_vs_oracle(dev, hw, n):
+    """FP_OP_SHUFDOWN (csrc/shufdown.hip): YOLOv5n-face's first ShuffleV2Block (32 -> 128 channels, stride 2: both branches, cat
+    and channel_shuffle in one kernel, split-MFMA 1x1 convs) against the oracle block (y5/models/common.py:127-176 restated) and
+    against the four-op form, on maps whose 4 x 16 output tiles overhang (11 x 13, 1 x 1, 5 x 17), divide (32 x 48) and at the
+    network's own 160 x 160."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    from oracle import yolo_ref
+    rng = np.random.default_rng(hw[0] * 7 + hw[1])
+    blk = Y.ShuffleV2Block(32, 128, 2)
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), 660 + hw[0]))
+    x = rng.normal(0, 1, (n, 32) + hw).astype(np.float32)
+    pb = PlanBuilder(n)
+    blk.emit(pb, pb.new_buf(hw[0], hw[1], 32).view())
+    assert [op.kind for op in pb.ops] == [L.OP_SHUFDOWN] and pb.ops[0].flags == L.OPF_SPLIT3
+    got = _run_yolo_block(blk.to(dev), x, dev)
+    with torch.no_grad():
+        want = yolo_ref._shuffle_block({k: v.cpu() for k, v in blk.state_dict().items()}, "", torch.from_numpy(x), 2).numpy()
+    assert got.shape[0] == n and got[:, :128].shape == want.shape
+    assert rel_err(got[:, :128], want) < 1e-5
+    Y.ShuffleV2Block.FUSE_DOWN = False
+    try:
+        pb = PlanBuilder(n)
+        blk.emit(pb, pb.new_buf(hw[0], hw[1], 32).view())
+        assert L.OP_SHUFDOWN not in [op.kind for op in pb.ops]
+        four = _run_yolo_block(blk, x, dev)
+    finally:
+        Y.ShuffleV2Block.FUSE_DOWN = True
+    assert np.abs(got[:, :128] - four[:, :128]).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize("c,hw,fuse_bn", [(32, (72, 88), False), (24, (40, 136), True), (16, (64, 64), True)])
 def test_yolo_stem_fused_kernel_matches_unfused_ops(dev, c, hw, fuse_bn):
     """FP_OP_YSTEM (stem_1 -> LDS -> stem_2a + maxpool, csrc/ystem.hip) against the five separate ops on ragged maps

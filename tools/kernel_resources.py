@@ -30,6 +30,9 @@ def main():
             m = re.search(pat, ln)
             if m and cur is not None:
                 cur[key] = int(m.group(1))
+    if not rows:                       # the compile failed: show why (c++filt without arguments would wait on stdin)
+        sys.stderr.write(out[-3000:])
+        return 1
     names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True,
                            text=True).stdout.split("\n")
     for r, n in zip(rows, names):
