@@ -123,6 +123,9 @@ int fp_launch_dwblock_x6(const fp_op& op, const float* weights, float* arena, hi
 bool fp_shufdown_supported(const fp_op& op);     // FP_OP_SHUFDOWN: a whole stride-2 ShuffleV2Block (shufdown.hip)
 long fp_shufdown_w_floats(const fp_op& op);
 int fp_launch_shufdown(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_shufunit_supported(const fp_op& op);     // FP_OP_SHUFUNIT: a whole stride-1 ShuffleV2Block (shufdown.hip)
+long fp_shufunit_w_floats(const fp_op& op);
+int fp_launch_shufunit(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pwx6_eligible(const fp_op& op);     // CONV with FP_OPF_SPLIT3: pointwise conv on the bf16x6 split-MFMA kernel (pwx6.hip)
 long fp_pwx6_w_floats(const fp_op& op);
 int fp_pwx6_mt(const fp_op& op);

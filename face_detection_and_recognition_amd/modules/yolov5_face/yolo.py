@@ -263,6 +263,7 @@ class ShuffleV2Block(_NoCompute):
 
     FUSE = True   # class-wide switch: False emits the unfused DWCONV + CONV pairs (A/B parity tests)
     FUSE_DOWN = True   # the whole stride-2 block as one FP_OP_SHUFDOWN where csrc/shufdown.hip has the shape (32 -> 128 channels)
+    FUSE_UNIT = True   # the whole stride-1 block as one FP_OP_SHUFUNIT where it has the width (128 channels)
 
     def emit(self, pb, x, out=None):
         """out: optional View (C = oup) the block writes into, e.g. a channel slice of a later Concat's buffer."""
@@ -278,6 +279,10 @@ class ShuffleV2Block(_NoCompute):
             b1 = self.branch1
             pb.shufdown(x, npy(b1[0].weight), _bn_sb(b1[1]), npy(b1[2].weight), _bn_sb(b1[3]),
                         npy(b2[0].weight), _bn_sb(b2[1]), npy(b2[3].weight), _bn_sb(b2[4]), npy(b2[5].weight), _bn_sb(b2[6]),
+                        View(ob, oc, self.oup))
+            return out
+        if s == 1 and ShuffleV2Block.FUSE and ShuffleV2Block.FUSE_UNIT and pb.shufunit_supported(x, View(ob, oc, self.oup), self.bf):
+            pb.shufunit(x, npy(b2[0].weight), _bn_sb(b2[1]), npy(b2[3].weight), _bn_sb(b2[4]), npy(b2[5].weight), _bn_sb(b2[6]),
                         View(ob, oc, self.oup))
             return out
         if s == 1:

@@ -786,6 +786,50 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * ((pix + opix) * cin + opix * (cin + cb) + pix * (cin + cb) + (pix + opix) * cb + opix * 2 * cb))
         return out
 
+    # branch widths csrc/shufdown.hip's stride-1 kernel (shufunit_x6_kernel) is instantiated for
+    SHUFUNIT_WIDTHS = (64,)
+
+    @classmethod
+    def shufunit_supported(cls, x, out, cb):
+        """Mirror of fp_shufunit_supported (csrc/shufdown.hip): a whole stride-1 ShuffleV2Block as one op."""
+        if not cls.X6 or cb not in cls.SHUFUNIT_WIDTHS or x.C != 2 * cb or out.C != 2 * cb or out.cmul != 1 or x.buf is out.buf:
+            return False
+        if (out.H, out.W) != (x.H, x.W) or x.buf.rowpad or out.buf.rowpad:
+            return False
+        for v in (x, out):
+            if v.buf.ld % 4 or (v.buf.off + v.coff) % 4 or v.buf.ns % 4 or v.buf.ns < v.H * v.W * v.buf.ld:
+                return False
+        return True
+
+    def shufunit(self, x, pw1, pw1_aff, dw2, dw2_aff, pw2, pw2_aff, out):
+        """A whole stride-1 ShuffleV2Block (y5/models/common.py:127-176) as ONE op (FP_OP_SHUFUNIT, csrc/shufdown.hip):
+        x1, x2 = x.chunk(2); branch2(x2) = 1x1 + BN + SiLU -> dw3x3 + BN -> 1x1 + BN + SiLU; out[2c] = x1[c], out[2c + 1] = branch2[c].
+        The parameter block's layout is facepath.h "SHUFUNIT"."""
+        cb = pw1.shape[0]
+        assert self.shufunit_supported(x, out, cb)
+        assert pw1.shape[:2] == (cb, cb) and dw2.shape == (cb, 1, 3, 3) and pw2.shape[:2] == (cb, cb)
+        op = self._base(L.OP_SHUFUNIT, x, out, out.H, out.W)
+        op.Cout, op.Cmid = 2 * cb, cb
+        op.KH = op.KW = 3
+        op.stride = 1
+        op.pad_t = op.pad_l = 1
+        op.act = op.act2 = L.ACT_SILU
+        op.flags |= L.OPF_SPLIT3
+        ks = r = cb // 32
+
+        def planes(a):
+            return np.ascontiguousarray(a).reshape(-1).view(np.float32)
+        w_1 = split3_bf16(np.asarray(pw1, np.float32).reshape(cb, cb)).reshape(3, r, 32, ks, 32).transpose(1, 0, 3, 2, 4)   # [r][3][ks][g'][k']
+        w_2 = split3_bf16(np.asarray(pw2, np.float32).reshape(cb, cb)).reshape(3, cb, r, 32).transpose(2, 0, 1, 3)           # [r][3][co][g']
+        blob = [planes(w_1), pad_vec(pw1_aff[0], cb), pad_vec(pw1_aff[1], cb),
+                pack_dw_weight(dw2, cb), pad_vec(dw2_aff[0], cb), pad_vec(dw2_aff[1], cb),
+                planes(w_2), pad_vec(pw2_aff[0], cb), pad_vec(pw2_aff[1], cb)]
+        op.w_off = self.add_weight(np.concatenate(blob))
+        self.ops.append(op)
+        pix = x.H * x.W
+        self.alg_bytes.append(4 * self.N * pix * 6 * cb)     # SURVEY 8(d): three convs of cb channels, input once + output once each
+        return out
+
     def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
         """First conv of a network reading u8 frames itself (FP_OP_STEM_U8): KxK (3 or 5) stride 2, Cout <= 64, dense
         output buffer.  u8 = (H, W, frame_h, frame_w, ext_index): the H x W letterbox canvas is resampled from the
@@ -1083,7 +1127,7 @@ class CompiledPlan:
             if op.flags & L.OPF_IN_UP2:                          # the leading res_C channels come from the half-size map
                 b_in = op.H * op.W * (op.Cin - op.res_C) * 4 + op.res_H * op.res_W * op.res_C * 4
         cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_BLAZECHAIN, L.OP_YSTEM, L.OP_YSTEM_U8,
-                                L.OP_STEM_U8, L.OP_SHUFDOWN) else op.Cin
+                                L.OP_STEM_U8, L.OP_SHUFDOWN, L.OP_SHUFUNIT) else op.Cin
         oh, ow = (op.H, op.W) if k in (L.OP_COPY, L.OP_L2NORM) else (op.OH, op.OW)
         b_out = oh * ow * cout * 4 * (2 if op.res_mode == L.RES_SHUFFLE2 else 1)
         b_res = 0
@@ -1115,6 +1159,8 @@ class CompiledPlan:
             f = op.Cmid * opix * (9 * op.Cin + op.Cin * op.Cout)
         elif k == L.OP_DWBLOCK:
             f = op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cout)
+        elif k == L.OP_SHUFUNIT:
+            f = opix * (2 * op.Cmid * op.Cmid + 9 * op.Cmid)
         elif k == L.OP_SHUFDOWN:   # branch1: dw + 1x1; branch2: 1x1 at full resolution, dw, 1x1
             f = opix * (9 * op.Cin + op.Cin * op.Cmid) + op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cmid)
         else:

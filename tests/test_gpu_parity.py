@@ -1728,6 +1728,37 @@ def test_yolo_shufflev2_stride2_block_in_one_kernel_vs_oracle(dev, hw, n):
     assert np.abs(got[:, :128] - four[:, :128]).max() <= 2e-6 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("hw,n", [((11, 13), 3), ((32, 48), 2), ((1, 1), 2), ((80, 80), 5), ((9, 33), 4)])
+def test_yolo_shufflev2_stride1_block_in_one_kernel_vs_oracle(dev, hw, n):
+    """FP_OP_SHUFUNIT (csrc/shufdown.hip shufunit_x6_kernel): YOLOv5n-face's 128-channel stride-1 ShuffleV2Block (chunk, branch2,
+    cat and channel_shuffle in one kernel) against the oracle block and against the two-op form (pointwise conv + FP_OP_DWPW), on
+    maps whose 8 x 16 tiles overhang, divide, and at the network's own 80 x 80."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    from oracle import yolo_ref
+    rng = np.random.default_rng(hw[0] * 5 + hw[1])
+    blk = Y.ShuffleV2Block(128, 128, 1)
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), 670 + hw[0]))
+    x = rng.normal(0, 1, (n, 128) + hw).astype(np.float32)
+    pb = PlanBuilder(n)
+    blk.emit(pb, pb.new_buf(hw[0], hw[1], 128).view())
+    assert [op.kind for op in pb.ops] == [L.OP_SHUFUNIT] and pb.ops[0].flags == L.OPF_SPLIT3
+    got = _run_yolo_block(blk.to(dev), x, dev)
+    with torch.no_grad():
+        want = yolo_ref._shuffle_block({k: v.cpu() for k, v in blk.state_dict().items()}, "", torch.from_numpy(x), 1).numpy()
+    assert got[:, :128].shape == want.shape
+    np.testing.assert_array_equal(got[:, 0:128:2], x[:, :64])                   # the x1 half passes through bit for bit
+    assert rel_err(got[:, :128], want) < 1e-5
+    Y.ShuffleV2Block.FUSE_UNIT = False
+    try:
+        pb = PlanBuilder(n)
+        blk.emit(pb, pb.new_buf(hw[0], hw[1], 128).view())
+        assert L.OP_SHUFUNIT not in [op.kind for op in pb.ops]
+        two = _run_yolo_block(blk, x, dev)
+    finally:
+        Y.ShuffleV2Block.FUSE_UNIT = True
+    assert np.abs(got[:, :128] - two[:, :128]).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize("c,hw,fuse_bn", [(32, (72, 88), False), (24, (40, 136), True), (16, (64, 64), True)])
 def test_yolo_stem_fused_kernel_matches_unfused_ops(dev, c, hw, fuse_bn):
     """FP_OP_YSTEM (stem_1 -> LDS -> stem_2a + maxpool, csrc/ystem.hip) against the five separate ops on ragged maps
