@@ -132,6 +132,43 @@ def test_stem_with_depthwise_op_validation(lib):
         assert lib.fp_plan_validate(bad, len(ops), weights.size, arena) == (-1 if ops[1].kind != L.OP_CONV else -3)
 
 
+def test_shufflev2_block_ops_validation(lib):
+    """FP_OP_SHUFDOWN / FP_OP_SHUFUNIT (ABI 10; csrc/shufdown.hip): the plans the YOLOv5n-face blocks emit validate on the host; other
+    shapes, an output that aliases the input, a parameter block that runs past the weights and stray flags are refused."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    for blk, cin, kind in ((Y.ShuffleV2Block(32, 128, 2), 32, L.OP_SHUFDOWN), (Y.ShuffleV2Block(128, 128, 1), 128, L.OP_SHUFUNIT)):
+        pb = PlanBuilder(2)
+        blk.emit(pb, pb.new_buf(24, 36, cin).view())
+        assert [op.kind for op in pb.ops] == [kind] and validate_on_host(pb) == 0
+        ops, weights, arena = pb.finish()
+
+        def rc_with(**kw):
+            op = L.FpOp.from_buffer_copy(pb.ops[0])
+            for k, v in kw.items():
+                setattr(op, k, v)
+            return lib.fp_plan_validate((L.FpOp * 1)(op), 1, len(weights), arena)
+        assert rc_with() == 0
+        assert rc_with(Cmid=32) == -3 and rc_with(Cin=64) in (-3, -1) and rc_with(flags=0) == -3 and rc_with(act2=L.ACT_NONE) == -3
+        assert rc_with(w_off=len(weights) - 64) == -2                        # the parameter block would run past the weights
+        assert rc_with(w_off=pb.ops[0].w_off + 2) == -3                      # 16-byte alignment of the block
+        if kind == L.OP_SHUFUNIT:
+            assert rc_with(out_off=pb.ops[0].in_off) == -3                   # in place: tiles read their neighbours' pixels
+            assert rc_with(stride=2) in (-3, -1)
+        else:
+            assert rc_with(H=23) in (-3, -1) and rc_with(stride=1) in (-3, -1)
+    # switches off -> the op-by-op forms
+    for name in ("FUSE_DOWN", "FUSE_UNIT"):
+        setattr(Y.ShuffleV2Block, name, False)
+    try:
+        for blk, cin in ((Y.ShuffleV2Block(32, 128, 2), 32), (Y.ShuffleV2Block(128, 128, 1), 128)):
+            pb = PlanBuilder(2)
+            blk.emit(pb, pb.new_buf(24, 36, cin).view())
+            assert not {L.OP_SHUFDOWN, L.OP_SHUFUNIT} & {op.kind for op in pb.ops} and validate_on_host(pb) == 0
+    finally:
+        for name in ("FUSE_DOWN", "FUSE_UNIT"):
+            setattr(Y.ShuffleV2Block, name, True)
+
+
 def test_blazeface_plans_validate_at_any_batch(lib):
     """The band rules of the pair kernels depend on the batch (fp_blazepair_band_rows: fewer, longer bands when there are many
     images): every batch size must still give a plan the validator accepts (a 64-row band on the 64 x 64 map -- one band per
