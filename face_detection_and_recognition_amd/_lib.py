@@ -15,7 +15,7 @@ ABI_VERSION = 10
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_YSTEM_U8, OP_STEM_U8, OP_DWBLOCK, OP_BLAZEPAIR, OP_BLAZECHAIN, OP_SHUFDOWN, OP_SHUFUNIT = 10, 11, 12, 13, 14, 15, 16
+OP_YSTEM_U8, OP_STEM_U8, OP_DWBLOCK, OP_BLAZEPAIR, OP_BLAZECHAIN, OP_SHUFDOWN, OP_SHUFUNIT, OP_YSTEM2 = 10, 11, 12, 13, 14, 15, 16, 17
 # fp_act
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SILU = 0, 1, 2, 3
 # fp_res_mode

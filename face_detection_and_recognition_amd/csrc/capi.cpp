@@ -98,7 +98,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   const bool ext_in = op.kind == FP_OP_YSTEM_U8 || op.kind == FP_OP_STEM_U8;   // input in an external buffer (checked at launch)
   const int Cout = (op.kind == FP_OP_CONV || op.kind == FP_OP_BLAZEBLOCK || op.kind == FP_OP_DWPW ||
                     op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_BLAZECHAIN || op.kind == FP_OP_YSTEM ||
-                    op.kind == FP_OP_SHUFDOWN || op.kind == FP_OP_SHUFUNIT || ext_in) ? op.Cout : op.Cin;
+                    op.kind == FP_OP_SHUFDOWN || op.kind == FP_OP_SHUFUNIT || op.kind == FP_OP_YSTEM2 || ext_in) ? op.Cout : op.Cin;
   if (op.reserved0 != 0 || (op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_BLAZECHAIN && op.kind != FP_OP_SHUFDOWN && op.kind != FP_OP_SHUFUNIT && op.Cmid != 0)) return FP_ERR_INVALID_ARG;
   if (Cout <= 0 || op.out_cmul < 1 || op.in_ld < op.Cin) return FP_ERR_INVALID_ARG;
   // row-padded views (facepath.h FP_OPF_*): which ops take them, and their extent including the pads
@@ -120,7 +120,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   }
   if ((op.flags & FP_OPF_IN_DW) && (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3))) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW && op.kind != FP_OP_BLAZECHAIN &&
-      op.kind != FP_OP_SHUFDOWN && op.kind != FP_OP_SHUFUNIT)
+      op.kind != FP_OP_SHUFDOWN && op.kind != FP_OP_SHUFUNIT && op.kind != FP_OP_YSTEM2)
     return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_DWPW && !fp_dwpwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !(op.flags & FP_OPF_OUT_DW) && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op))
@@ -164,7 +164,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
 
   if (op.kind == FP_OP_CONV || op.kind == FP_OP_DWCONV || op.kind == FP_OP_MAXPOOL || op.kind == FP_OP_BLAZEBLOCK ||
       op.kind == FP_OP_DWPW || op.kind == FP_OP_DWBLOCK || op.kind == FP_OP_BLAZEPAIR || op.kind == FP_OP_BLAZECHAIN ||
-      op.kind == FP_OP_YSTEM || op.kind == FP_OP_SHUFDOWN || op.kind == FP_OP_SHUFUNIT || ext_in) {
+      op.kind == FP_OP_YSTEM || op.kind == FP_OP_SHUFDOWN || op.kind == FP_OP_SHUFUNIT || op.kind == FP_OP_YSTEM2 || ext_in) {
     if (op.KH <= 0 || op.KW <= 0 || op.stride <= 0 || op.pad_t < 0 || op.pad_l < 0) return FP_ERR_INVALID_ARG;
     // every output pixel must have at least its first tap row/col addressable without overflow of int math
     if ((int64_t)(OH - 1) * op.stride - op.pad_t >= op.H || (int64_t)(OW - 1) * op.stride - op.pad_l >= op.W)
@@ -206,6 +206,12 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     // one parameter block at w_off (facepath.h SHUFDOWN); the shapes the kernel exists for are fp_shufdown_supported's
     if (!fp_shufdown_supported(op)) return FP_ERR_UNSUPPORTED;
     if (!span_ok(op.w_off, fp_shufdown_w_floats(op), weight_floats)) return FP_ERR_BOUNDS;
+  } else if (op.kind == FP_OP_YSTEM2) {
+    // parameter block at w_off, the pooled map in the res view (facepath.h YSTEM2)
+    if (!fp_ystem2_supported(op)) return FP_ERR_UNSUPPORTED;
+    if (!span_ok(op.w_off, fp_ystem2_w_floats(op), weight_floats)) return FP_ERR_BOUNDS;
+    const int64_t res_ext = (int64_t)(op.N - 1) * op.res_ns + ((int64_t)op.OH * op.OW - 1) * op.res_ld + op.res_C;
+    if (!span_ok(op.res_off, res_ext, arena_floats)) return FP_ERR_BOUNDS;
   } else if (op.kind == FP_OP_SHUFUNIT) {
     if (!fp_shufunit_supported(op)) return FP_ERR_UNSUPPORTED;
     if (!span_ok(op.w_off, fp_shufunit_w_floats(op), weight_floats)) return FP_ERR_BOUNDS;
@@ -290,6 +296,7 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     case FP_OP_STEM_U8:
     case FP_OP_SHUFDOWN:
     case FP_OP_SHUFUNIT:
+    case FP_OP_YSTEM2:
       return FP_OK;
     default:
       return FP_ERR_UNSUPPORTED;
@@ -383,6 +390,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
     case FP_OP_SHUFUNIT:
       snprintf(buf, sizeof(buf), "shufunit_x6_kernel<%d>", op->Cmid);
       return buf;
+    case FP_OP_YSTEM2: return "ystem2_x6_kernel";
     case FP_OP_STEM_U8:
       if (fp_stem_u8_band_eligible(*op)) return "stem5_u8_band_kernel";
       snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d, true>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
@@ -421,6 +429,7 @@ static int launch_op(const fp_op& op, const float* weights, float* arena, const 
     case FP_OP_BLAZECHAIN: return fp_launch_blazechain(op, weights, arena, s);
     case FP_OP_SHUFDOWN: return fp_launch_shufdown(op, weights, arena, s);
     case FP_OP_SHUFUNIT: return fp_launch_shufunit(op, weights, arena, s);
+    case FP_OP_YSTEM2: return fp_launch_ystem2(op, weights, arena, s);
     case FP_OP_YSTEM: return fp_launch_ystem(op, weights, arena, s);
     case FP_OP_YSTEM_U8: return fp_launch_ystem_u8(op, weights, arena, ext, n_ext, s);
     case FP_OP_STEM_U8: return fp_launch_stem_u8(op, weights, arena, ext, n_ext, s);

@@ -126,6 +126,9 @@ int fp_launch_shufdown(const fp_op& op, const float* weights, float* arena, hipS
 bool fp_shufunit_supported(const fp_op& op);     // FP_OP_SHUFUNIT: a whole stride-1 ShuffleV2Block (shufdown.hip)
 long fp_shufunit_w_floats(const fp_op& op);
 int fp_launch_shufunit(const fp_op& op, const float* weights, float* arena, hipStream_t s);
+bool fp_ystem2_supported(const fp_op& op);       // FP_OP_YSTEM2: stem_2b + cat + stem_3 of YOLOv5-face's StemBlock (ystem2.hip)
+long fp_ystem2_w_floats(const fp_op& op);
+int fp_launch_ystem2(const fp_op& op, const float* weights, float* arena, hipStream_t s);
 bool fp_pwx6_eligible(const fp_op& op);     // CONV with FP_OPF_SPLIT3: pointwise conv on the bf16x6 split-MFMA kernel (pwx6.hip)
 long fp_pwx6_w_floats(const fp_op& op);
 int fp_pwx6_mt(const fp_op& op);

@@ -127,6 +127,7 @@ class StemBlock(_NoCompute):
         self.stem_3 = Conv(c2 * 2, c2, 1, 1, 0)
 
     FUSE = True   # class-wide switch: False emits the five separate ops (A/B parity tests)
+    FUSE_TAIL = True   # stem_2b + cat + stem_3 as one FP_OP_YSTEM2 (csrc/ystem2.hip) where the block has its shape (c = 32)
 
     @staticmethod
     def _sb(conv):
@@ -155,6 +156,17 @@ class StemBlock(_NoCompute):
             sc2, bi2 = self._sb(self.stem_2a)
             pb.ystem(x, npy(s1c.conv.weight), sc1, bi1, npy(self.stem_2a.conv.weight), sc2, bi2, a.view(0, cpad(c // 2)),
                      cat.view(c, c), u8=u8)
+            s2b, s3 = self.stem_2b, self.stem_3
+            y = pb.new_buf(H1 // 2, W1 // 2, c).view() if out is None else out
+            if (StemBlock.FUSE_TAIL and c == 32 and s2b.act and s3.act and s2b.k == 3 and s2b.s == 2 and s2b.p == 1 and
+                    pb.ystem2_supported(a.view(0, c // 2), cat.view(c, c), y)):
+                # stem_2b -> cat -> stem_3 in one kernel (FP_OP_YSTEM2): stem_2b's output never reaches HBM
+                pb.ystem2(a.view(0, c // 2), cat.view(c, c), npy(s2b.conv.weight), self._sb(s2b), npy(s3.conv.weight), self._sb(s3), y)
+                pb.free(a)
+                pb.free(cat)
+                return y
+            if out is None:
+                pb.free(y.buf)
             self.stem_2b.emit(pb, a.view(0, c // 2), out=cat.view(0, c))
             pb.free(a)
             y = self.stem_3.emit(pb, cat.view(), out=out)

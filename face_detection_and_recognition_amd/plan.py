@@ -911,6 +911,48 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * (H * W * 3 + H1 * W1 * c1 + H1 * W1 * c1 + H1 * W1 * c2))
         return a_out
 
+    @classmethod
+    def ystem2_supported(cls, a, pool, out):
+        """Mirror of fp_ystem2_supported (csrc/ystem2.hip): stem_2b + cat + stem_3 of YOLOv5n-face's StemBlock (c = 32) as one op."""
+        if not cls.X6 or a.C != 16 or pool.C != 32 or out.C != 32 or out.cmul != 1 or a.H % 2 or a.W % 2:
+            return False
+        if (out.H, out.W) != (a.H // 2, a.W // 2) or (pool.H, pool.W) != (out.H, out.W):
+            return False
+        for v in (a, pool, out):
+            if v.buf.rowpad or v.buf.ld % 4 or (v.buf.off + v.coff) % 4 or v.buf.ns % 4 or v.buf.ns < v.H * v.W * v.buf.ld:
+                return False
+        return out.buf is not a.buf and out.buf is not pool.buf
+
+    def ystem2(self, a, pool, w2b, aff2b, w3, aff3, out):
+        """The tail of YOLOv5-face's StemBlock (y5/models/common.py:58-73) as ONE op (FP_OP_YSTEM2, csrc/ystem2.hip):
+        out = stem_3(cat(stem_2b(a), pool)), both convs + (BN) + SiLU.  *_aff = (scale or None, bias).  Layout: facepath.h "YSTEM2"."""
+        assert self.ystem2_supported(a, pool, out) and w2b.shape == (32, 16, 3, 3) and w3.shape[:2] == (32, 64)
+        op = self._base(L.OP_YSTEM2, a, out, out.H, out.W)
+        op.Cout = 32
+        op.KH = op.KW = 3
+        op.stride = 2
+        op.pad_t = op.pad_l = 1
+        op.act = op.act2 = L.ACT_SILU
+        op.flags |= L.OPF_SPLIT3
+        op.res_ld, op.res_ns = pool.buf.ld, pool.buf.ns
+        op.res_off = pool.buf.off + pool.coff
+        op.res_C, op.res_H, op.res_W = 32, pool.H, pool.W
+
+        def planes(x):
+            return np.ascontiguousarray(x).reshape(-1).view(np.float32)
+
+        def aff(sb):
+            return [np.ones(32, np.float32) if sb[0] is None else pad_vec(sb[0], 32), pad_vec(sb[1], 32)]
+        k2 = np.zeros((32, 160), np.float32)                                    # k = (ky*3 + kx)*16 + c, padded to five slabs
+        k2[:, :144] = np.asarray(w2b, np.float32).transpose(0, 2, 3, 1).reshape(32, 144)
+        p2 = split3_bf16(k2).reshape(3, 32, 5, 32).transpose(2, 0, 1, 3)        # [slab][3][co][k']
+        p3 = split3_bf16(np.asarray(w3, np.float32).reshape(32, 64)).reshape(3, 32, 2, 32).transpose(2, 0, 1, 3)
+        op.w_off = self.add_weight(np.concatenate([planes(p2)] + aff(aff2b) + [planes(p3)] + aff(aff3)))
+        self.ops.append(op)
+        pix, opix = a.H * a.W, out.H * out.W
+        self.alg_bytes.append(4 * self.N * (pix * 16 + opix * 32 + opix * 64 + opix * 32))   # SURVEY 8(d): the two convs
+        return out
+
     def maxpool(self, x, out, k, stride, pad):
         assert out.C == x.C
         op = self._base(L.OP_MAXPOOL, x, out, out.H, out.W)
@@ -1127,12 +1169,14 @@ class CompiledPlan:
             if op.flags & L.OPF_IN_UP2:                          # the leading res_C channels come from the half-size map
                 b_in = op.H * op.W * (op.Cin - op.res_C) * 4 + op.res_H * op.res_W * op.res_C * 4
         cout = op.Cout if k in (L.OP_CONV, L.OP_BLAZEBLOCK, L.OP_DWPW, L.OP_DWBLOCK, L.OP_BLAZEPAIR, L.OP_BLAZECHAIN, L.OP_YSTEM, L.OP_YSTEM_U8,
-                                L.OP_STEM_U8, L.OP_SHUFDOWN, L.OP_SHUFUNIT) else op.Cin
+                                L.OP_STEM_U8, L.OP_SHUFDOWN, L.OP_SHUFUNIT, L.OP_YSTEM2) else op.Cin
         oh, ow = (op.H, op.W) if k in (L.OP_COPY, L.OP_L2NORM) else (op.OH, op.OW)
         b_out = oh * ow * cout * 4 * (2 if op.res_mode == L.RES_SHUFFLE2 else 1)
         b_res = 0
         if k in (L.OP_YSTEM, L.OP_YSTEM_U8):
             b_res = (op.OH // 2) * (op.OW // 2) * op.res_C * 4   # the pooled stem_1 map it also writes
+        elif k == L.OP_YSTEM2:
+            b_res = op.OH * op.OW * op.res_C * 4                 # the pooled map it reads
         elif (k in (L.OP_CONV, L.OP_DWPW) and op.res_off != op.in_off and
               op.res_mode in (L.RES_ADD_BEFORE_ACT, L.RES_ADD_AFTER_ACT, L.RES_SHUFFLE2)):
             b_res = oh * ow * op.res_C * 4                       # a residual that is not the op's own input (the block
@@ -1161,6 +1205,8 @@ class CompiledPlan:
             f = op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cout)
         elif k == L.OP_SHUFUNIT:
             f = opix * (2 * op.Cmid * op.Cmid + 9 * op.Cmid)
+        elif k == L.OP_YSTEM2:
+            f = opix * (9 * op.Cin * op.Cout + 2 * op.Cout * op.Cout)
         elif k == L.OP_SHUFDOWN:   # branch1: dw + 1x1; branch2: 1x1 at full resolution, dw, 1x1
             f = opix * (9 * op.Cin + op.Cin * op.Cmid) + op.H * op.W * op.Cin * op.Cmid + opix * (9 * op.Cmid + op.Cmid * op.Cmid)
         else:

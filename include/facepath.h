@@ -85,6 +85,8 @@ enum fp_op_kind {
   FP_OP_DWBLOCK = 12,   /* a WHOLE Depth_Wise block (mobile_facenet.py:67-88) in one kernel: 1x1 expand (+BN, PReLU) ->
                            dw3x3 stride 1 (+BN, PReLU) -> 1x1 project (+BN) [+ x]; the expanded tensor (Cmid channels)
                            lives in LDS only.  Shapes: see "DWBLOCK" below; anything else fails validation */
+  FP_OP_YSTEM2 = 17,    /* ABI 10.  the tail of YOLOv5-face's StemBlock (y5/models/common.py:58-73) in one kernel: stem_2b (3x3 stride 2, c/2 -> c,
+                           SiLU) -> cat with the pooled stem_1 map -> stem_3 (1x1, 2c -> c, SiLU); stem_2b's output never reaches HBM.  See "YSTEM2" */
   FP_OP_SHUFUNIT = 16,  /* ABI 10.  a WHOLE stride-1 ShuffleV2Block (y5/models/common.py:127-176): x1, x2 = x.chunk(2); branch2(x2) = 1x1 + BN
                            + SiLU -> dw3x3 + BN -> 1x1 + BN + SiLU; out = channel_shuffle(cat(x1, branch2)) in one kernel.  See "SHUFUNIT" */
   FP_OP_SHUFDOWN = 15   /* ABI 10.  a WHOLE stride-2 ShuffleV2Block (y5/models/common.py:127-176) in one kernel: branch1 = dw3x3 s2 + BN
@@ -281,8 +283,13 @@ typedef struct fp_op {
  *            block at w_off: [2 rounds][3 planes][2 slabs][32 g][32 k] first 1x1 of branch2 (on channels 64 .. 127 of x);  [64] scale,
  *            [64] bias;  [9][64] depthwise taps, [64] BN scale, [64] BN bias;  [2 rounds][3 planes][64 co][32 g] second 1x1;  [64] scale,
  *            [64] bias.  out[2 c] = x[c] (c < 64), out[2 c + 1] = branch2[c].
+ *   YSTEM2 : in = a (stem_2a's output: H x W even, Cin = 16 channels), res_* = the pooled stem_1 map (res_H x res_W = OH x OW = H/2 x W/2,
+ *            res_C = 32 channels), out = stem_3's output (Cout = 32), 3x3 stride 2 pad 1, act = act2 = FP_ACT_SILU, flags = FP_OPF_SPLIT3.
+ *            Parameter block at w_off: [5 slabs][3 planes][32 co][32 k] stem_2b with k = (ky*3 + kx)*16 + c (zero for k >= 144);
+ *            [32] scale, [32] bias;  [2 slabs][3 planes][32 co][32 k] stem_3 (k: stem_2b's 32 channels, then the pooled map's);  [32] scale,
+ *            [32] bias (scale = 1 where the BatchNorm is folded into the conv).
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env; 10 = FP_OP_SHUFDOWN, FP_OP_SHUFUNIT.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env; 10 = FP_OP_SHUFDOWN, FP_OP_SHUFUNIT, FP_OP_YSTEM2.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

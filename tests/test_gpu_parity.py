@@ -1786,6 +1786,38 @@ def test_yolo_stem_fused_kernel_matches_unfused_ops(dev, c, hw, fuse_bn):
     assert rel_err(outs[True], outs[False]) < 2e-6
 
 
+@pytest.mark.parametrize("hw,n,fuse_bn", [((72, 88), 3, False), ((8, 8), 2, True), ((640, 640), 2, True), ((36, 132), 4, False), ((4, 4), 1, True)])
+def test_yolo_stem_tail_in_one_kernel_vs_oracle(dev, hw, n, fuse_bn):
+    """FP_OP_YSTEM2 (csrc/ystem2.hip): stem_2b -> cat -> stem_3 of the c = 32 StemBlock in one kernel, behind FP_OP_YSTEM: the whole
+    block against the oracle (common.py:58-73 restated) and against the three-op form (FP_OP_YSTEM + two convs), live and folded
+    BatchNorm, on maps whose 4 x 16 output tiles overhang (18 x 22, 2 x 2, 9 x 33, 1 x 1) and at 640 x 640."""
+    from face_detection_and_recognition_amd.modules.yolov5_face import yolo as Y
+    from oracle import yolo_ref
+    rng = np.random.default_rng(hw[0] + 3 * hw[1])
+    blk = Y.StemBlock(3, 32, 3, 2)
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), 720 + hw[0]))
+    if fuse_bn:
+        for m in (blk.stem_1, blk.stem_2a, blk.stem_2b, blk.stem_3):
+            m.fuse()
+    blk = blk.to(dev)
+    x = rng.uniform(-1, 1, (n, 3) + hw).astype(np.float32)
+    outs = {}
+    for flag in (True, False):
+        Y.StemBlock.FUSE_TAIL = flag
+        try:
+            pb = PlanBuilder(n)
+            blk.emit(pb, pb.new_buf(hw[0], hw[1], 4).view())
+            assert ([op.kind for op in pb.ops] == [L.OP_YSTEM, L.OP_YSTEM2]) == flag
+            outs[flag] = _run_yolo_block(blk, x, dev)[:, :32]
+        finally:
+            Y.StemBlock.FUSE_TAIL = True
+    with torch.no_grad():
+        want = yolo_ref._stem({k: v.cpu() for k, v in blk.state_dict().items()}, "", torch.from_numpy(x)).numpy()
+    assert outs[True].shape == want.shape
+    assert rel_err(outs[True], want) < 1e-5 and rel_err(outs[False], want) < 1e-5
+    assert rel_err(outs[True], outs[False]) < 2e-6
+
+
 @pytest.mark.parametrize("frame_hw", [(576, 1024), (360, 640), (97, 33), (640, 640), (1275, 1650)])
 def test_yolo_letterbox_fused_into_stem_is_bit_exact(dev, frame_hw):
     """FP_OP_YSTEM_U8 (the stem reads the u8 frames through fp_letterbox_tables; no fp32 canvas) against the stand-alone

@@ -156,6 +156,24 @@ def test_shufflev2_block_ops_validation(lib):
             assert rc_with(stride=2) in (-3, -1)
         else:
             assert rc_with(H=23) in (-3, -1) and rc_with(stride=1) in (-3, -1)
+    # the stem's tail (FP_OP_YSTEM2): emitted behind FP_OP_YSTEM for c = 32, refused for other shapes / a missing pooled view
+    stem = Y.StemBlock(3, 32, 3, 2)
+    pb = PlanBuilder(2)
+    stem.emit(pb, pb.new_buf(48, 64, 4).view())
+    assert [op.kind for op in pb.ops] == [L.OP_YSTEM, L.OP_YSTEM2] and validate_on_host(pb) == 0
+    ops, weights, arena = pb.finish()
+
+    def rc2(**kw):
+        op = L.FpOp.from_buffer_copy(pb.ops[1])
+        for k, v in kw.items():
+            setattr(op, k, v)
+        return lib.fp_plan_validate((L.FpOp * 1)(op), 1, len(weights), arena)
+    assert rc2() == 0 and rc2(res_C=16) == -3 and rc2(Cout=48) in (-3, -2, -1) and rc2(flags=0) == -3 and rc2(res_H=5) == -3
+    assert rc2(w_off=len(weights) - 64) == -2 and rc2(res_off=arena - 64) == -2
+    for c in (24, 16):                                                   # other widths keep the two convs
+        pb = PlanBuilder(2)
+        Y.StemBlock(3, c, 3, 2).emit(pb, pb.new_buf(48, 64, 4).view())
+        assert L.OP_YSTEM2 not in [op.kind for op in pb.ops] and validate_on_host(pb) == 0
     # switches off -> the op-by-op forms
     for name in ("FUSE_DOWN", "FUSE_UNIT"):
         setattr(Y.ShuffleV2Block, name, False)
