@@ -27,6 +27,7 @@ static fp_knobs read_knobs() {
   k.pwx6_small_maxk = env_int("FP_PWX6_SMALL_MAXK");
   k.pair_lds_min = env_int("FP_PAIR_LDS_MIN");
   k.x6_lds_min = env_int("FP_X6_LDS_MIN");
+  k.shuf_ldsw = env_int("FP_SHUF_LDSW");
   return k;
 }
 static fp_knobs g_knobs = read_knobs();

@@ -35,6 +35,7 @@ struct fp_knobs {
   int pwx6_small_maxk;   // FP_PWX6_SMALL_MAXK: K at or below which pwx6 takes its small tiles (lab)
   int pair_lds_min;      // FP_PAIR_LDS_MIN: blazepair kernels request at least this much LDS (lab: > 80 KiB = one workgroup per CU)
   int x6_lds_min;        // FP_X6_LDS_MIN: the same for the dwblock_x6 / x6d kernels (lab)
+  int shuf_ldsw;         // FP_SHUF_LDSW: shufdown_x6_kernel in its eight-wave, weights-in-LDS form (lab)
 };
 const fp_knobs& fp_get_knobs();
 

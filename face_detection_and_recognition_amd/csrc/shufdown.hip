@@ -39,13 +39,15 @@ struct ShufDownArgs {
   long in_ns, out_ns;
 };
 
-template <int KS, int CB>
+template <int KS, int CB, bool LDSW = false>
 struct SDCfg {
   static constexpr int CIN = 32 * KS, R = CB / 32, NCT = CB / 16;
   static constexpr int TH = 4, TW = 16;                      // output pixels of a tile
   static constexpr int ER = 2 * TH + 1, EC = 2 * TW + 1;     // input pixels under it
   static constexpr int NSLOT = ER * EC;                      // 297
-  static constexpr int NW = 4;                               // waves of a workgroup: NW / TH per output row of the tile (1: all channels; 2: half each)
+  // LDSW: eight waves, ONE workgroup per CU, all three weight matrices in LDS for the whole launch (rows of 32 bf16 at an 80-byte pitch:
+  // conflict-free fragment reads) instead of 48 KiB-per-wave-and-tile of fragment loads through the CU's texture path
+  static constexpr int NW = LDSW ? 8 : 4;                    // waves of a workgroup: NW / TH per output row of the tile (1: all channels; 2: half each)
   static constexpr int WPT = NW / TH, DWI = 2 * TH / NW;     // waves per pixel tile; depthwise items per thread
   static constexpr int MTE = (NSLOT + 15) / 16, NOWN = (MTE + NW - 1) / NW;
   static constexpr int LDE = 36;                             // floats per E slot (odd number of 16-byte units)
@@ -53,7 +55,8 @@ struct SDCfg {
   static constexpr int LDA = 40;                             // bf16 per D-tile pixel row (80 bytes: conflict-free fragment reads)
   static constexpr int DPL = TH * TW * LDA;
   static constexpr int PL = 11 * CIN + 2 * CB + 2 * CB + 11 * CB + 2 * CB;   // fp32 parameter rows kept in LDS
-  static constexpr int LDS_BYTES = EB * 4 + 3 * DPL * 2 + PL * 4;
+  static constexpr int WROWS = LDSW ? KS * 3 * CB + R * 3 * KS * 32 + R * 3 * CB : 0, WPITCH = 40;   // weight rows kept in LDS
+  static constexpr int LDS_BYTES = EB * 4 + 3 * DPL * 2 + PL * 4 + WROWS * WPITCH * 2;
   // parameter blob, in floats (two bf16 per float in the weight planes)
   static constexpr long O_B1DW = 0;                                    // [9][CIN] taps, [CIN] BN scale, [CIN] BN bias
   static constexpr long O_B1PW = O_B1DW + 11 * CIN;                    // [KS][3 planes][CB][32 k] bf16
@@ -64,14 +67,14 @@ struct SDCfg {
   static constexpr long O_W2 = O_DW2 + 11 * CB;                        // [R][3][CB co][32 g] bf16
   static constexpr long O_AFF2 = O_W2 + (long)R * 3 * CB * 16;         // [CB] scale, [CB] bias
   static constexpr long TOTAL = O_AFF2 + 2 * CB;
-  static_assert(LDS_BYTES <= 80 * 1024 && CB % 64 == 0 && NOWN * NW >= MTE && TH * TW * 8 == NW * 64 * DWI && WPT * TH == NW && NW == 4, "two workgroups per CU");
+  static_assert(LDS_BYTES <= (LDSW ? 160 : 80) * 1024 && CB % 64 == 0 && NOWN * NW >= MTE && TH * TW * 8 == NW * 64 * DWI && WPT * TH == NW, "two workgroups per CU");
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *(const u32x4*)p; }
 
-template <int KS, int CB>
-__global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
-  using K = SDCfg<KS, CB>;
+template <int KS, int CB, bool LDSW>
+__global__ __launch_bounds__((LDSW ? 512 : 256), (LDSW ? 1 : 2)) void shufdown_x6_kernel(ShufDownArgs p) {
+  using K = SDCfg<KS, CB, LDSW>;
   static_assert(KS == 1, "the E-image's 32 channels double as the tile's copy of x");
   constexpr int CIN = K::CIN, R = K::R, NCT = K::NCT, LDE = K::LDE, LDA = K::LDA, DPL = K::DPL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -87,6 +90,16 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
   const int l15 = lane & 15, q = lane >> 4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   const unsigned short* wb = (const unsigned short*)p.w;
+  unsigned short* Wl = (unsigned short*)(Pl + K::PL);                  // LDSW: [WROWS][WPITCH] bf16: b1's 1x1, then W1, then W2
+  constexpr int WR_B1 = 0, WR_W1 = KS * 3 * CB, WR_W2 = WR_W1 + R * 3 * KS * 32;
+  if (LDSW) {
+    for (int i = tid; i < K::WROWS * 4; i += 64 * K::NW) {            // a row = 32 bf16 = four 16-byte pieces
+      const int row = i >> 2, piece = i & 3;
+      const unsigned short* src = row < WR_W1 ? wb + 2 * K::O_B1PW + row * 32
+                                : row < WR_W2 ? wb + 2 * K::O_W1 + (row - WR_W1) * 32 : wb + 2 * K::O_W2 + (row - WR_W2) * 32;
+      *(u32x4*)(Wl + row * K::WPITCH + 8 * piece) = ldg16(src + 8 * piece);
+    }
+  }
 
   for (int i = tid; i < K::PL / 4; i += 64 * K::NW) {
     const int f = 4 * i;
@@ -94,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
                    : f < P_AFF2 ? K::O_DW2 + (f - P_DW2) : K::O_AFF2 + (f - P_AFF2);
     *(f32x4*)&Pl[f] = *(const f32x4*)(p.w + src);
   }
+  if (LDSW) __syncthreads();                             // the weight rows are read before the tile loop's first barrier
 
   // this thread's depthwise items: 16 consecutive output columns of one (row, channel quad) per 16 lanes
   const int txl = tid & 15, grp = tid >> 4;
@@ -128,7 +142,17 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
   int wofs = l15 * 32 + 8 * q;
   constexpr int NCW = NCT / K::WPT;                       // channel tiles of a wave
   const int ptile = wave % K::TH, ct0 = (wave / K::TH) * NCW;
-  auto load_w = [&](const unsigned short* slab, fp_frag3 (&w)[NCW]) {
+  const int lofs = l15 * K::WPITCH + 8 * q;               // LDSW: the same fragment in the LDS copy (80-byte rows)
+  auto load_w = [&](const unsigned short* slab, int lrow, fp_frag3 (&w)[NCW]) {     // slab: [3][CB][32] in the blob; lrow: its first LDS row
+    if (LDSW) {
+      const unsigned short* wp = Wl + (lrow + 16 * ct0) * K::WPITCH + lofs;
+#pragma unroll
+      for (int ct = 0; ct < NCW; ++ct) {
+        w[ct].h = *(const u32x4*)(wp + (16 * ct) * K::WPITCH), w[ct].m = *(const u32x4*)(wp + (CB + 16 * ct) * K::WPITCH);
+        w[ct].l = *(const u32x4*)(wp + (2 * CB + 16 * ct) * K::WPITCH);
+      }
+      return;
+    }
     const unsigned short* wp = slab + wofs + (16 * ct0) * 32;
 #pragma unroll
     for (int ct = 0; ct < NCW; ++ct)
@@ -143,6 +167,12 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
   };
   // the two 16-channel tiles of round r of the first 1x1: rows 16 gt + l15 of [3][32 g][32 k]
   auto load_w1 = [&](int r, fp_frag3& wa, fp_frag3& wc) {
+    if (LDSW) {
+      const unsigned short* b = Wl + (WR_W1 + r * 3 * 32) * K::WPITCH + lofs;
+      wa.h = *(const u32x4*)b, wa.m = *(const u32x4*)(b + 32 * K::WPITCH), wa.l = *(const u32x4*)(b + 64 * K::WPITCH);
+      wc.h = *(const u32x4*)(b + 16 * K::WPITCH), wc.m = *(const u32x4*)(b + 48 * K::WPITCH), wc.l = *(const u32x4*)(b + 80 * K::WPITCH);
+      return;
+    }
     const unsigned short* b = wb + 2 * K::O_W1 + (long)r * 3 * 32 * 32 + wofs;
     wa.h = ldg16(b), wa.m = ldg16(b + 1024), wa.l = ldg16(b + 2048);
     wc.h = ldg16(b + 512), wc.m = ldg16(b + 1024 + 512), wc.l = ldg16(b + 2048 + 512);
@@ -179,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
       xb[t] = *(const f32x4*)(px + 4);
     }
     fp_frag3 wb1[NCW];
-    load_w(wb + 2 * K::O_B1PW, wb1);                       // branch 1's 1x1: lands under the depthwise phase
+    load_w(wb + 2 * K::O_B1PW, WR_B1, wb1);                       // branch 1's 1x1: lands under the depthwise phase
     __syncthreads();                                       // the previous tile is done with the E-image and the D tile (first tile: the parameters are in LDS)
 #pragma unroll
     for (int t = 0; t < K::NOWN; ++t) {
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
         }
       }
       fp_frag3 w2[NCW];
-      load_w(wb + 2 * K::O_W2 + (long)r * 3 * CB * 32, w2);          // lands under the depthwise phase
+      load_w(wb + 2 * K::O_W2 + (long)r * 3 * CB * 32, WR_W2 + r * 3 * CB, w2);          // lands under the depthwise phase
       __syncthreads();                                     // E-image complete (and the previous 1x1 is done with the D tile)
       dw_phase(Pl + P_DW2, CB, 32 * r);
       if (r + 1 < R) load_w1(r + 1, wa, wc);
@@ -249,17 +279,18 @@ __global__ __launch_bounds__(256, 2) void shufdown_x6_kernel(ShufDownArgs p) {
   }
 }
 
-template <int KS, int CB>
+template <int KS, int CB, bool LDSW>
 int launch(const ShufDownArgs& a, hipStream_t s) {
-  using K = SDCfg<KS, CB>;
-  const hipError_t ae = hipFuncSetAttribute((const void*)shufdown_x6_kernel<KS, CB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  using K = SDCfg<KS, CB, LDSW>;
+  const hipError_t ae = hipFuncSetAttribute((const void*)shufdown_x6_kernel<KS, CB, LDSW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             K::LDS_BYTES);
   if (ae != hipSuccess) {
     fp_set_hip_error(ae);
     return FP_ERR_LAUNCH;
   }
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;       // persistent: two workgroups per CU, contiguous runs of tiles
-  hipLaunchKernelGGL((shufdown_x6_kernel<KS, CB>), dim3((unsigned)grid), dim3(64 * K::NW), K::LDS_BYTES, s, a);
+  const int slots = LDSW ? 256 : 512;                     // persistent: one / two workgroups per CU, contiguous runs of tiles
+  const int grid = a.ntiles < slots ? a.ntiles : slots;
+  hipLaunchKernelGGL((shufdown_x6_kernel<KS, CB, LDSW>), dim3((unsigned)grid), dim3(64 * K::NW), K::LDS_BYTES, s, a);
   FP_CHECK_LAUNCH();
   return FP_OK;
 }
@@ -529,7 +560,7 @@ int fp_launch_shufdown(const fp_op& op, const float* weights, float* arena, hipS
   a.tiles_x = (op.OW + 15) / 16;
   a.tiles_per_img = a.tiles_x * ((op.OH + SDCfg<1, 64>::TH - 1) / SDCfg<1, 64>::TH);
   a.ntiles = op.N * a.tiles_per_img;
-  return launch<1, 64>(a, s);
+  return fp_get_knobs().shuf_ldsw ? launch<1, 64, true>(a, s) : launch<1, 64, false>(a, s);
 }
 
 // FP_OP_SHUFUNIT: the stride-1 block, Cin = Cout = 128 (x and out dense 128-channel views), Cmid = 64, 3x3 stride 1 pad 1.
