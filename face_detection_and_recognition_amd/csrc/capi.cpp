@@ -386,7 +386,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
       snprintf(buf, sizeof(buf), "dwblock_kernel<%d, %d, %d, %d>", op->Cin, op->H, op->H == 28 ? 7 : op->H, op->H == 7 ? 3 : 1);
       return buf;
     case FP_OP_SHUFDOWN:
-      snprintf(buf, sizeof(buf), "shufdown_x6_kernel<%d, %d>", op->Cin / 32, op->Cmid);
+      snprintf(buf, sizeof(buf), "shufdown_x6_kernel<%d, %d, %s>", op->Cin / 32, op->Cmid, fp_get_knobs().shuf_ldsw ? "true" : "false");
       return buf;
     case FP_OP_SHUFUNIT:
       snprintf(buf, sizeof(buf), "shufunit_x6_kernel<%d>", op->Cmid);
