@@ -28,3 +28,16 @@ for n in (8, 1, 3, 100, 1025, 3000):
     e = p.out[:min(n, 3)].cpu().numpy().copy() if hasattr(p, "out") else None
     if base is None: base = e
     else: print("mobilefacenet batch", n, "max |diff| vs batch 8:", float(np.abs(e[:min(n,3)] - base[:min(n,3)]).max()))
+# YOLOv5n-face (whole-block ShuffleV2 kernels, stem tail): persistent grids of 512 workgroups against 1 .. 20 000 tiles
+from face_detection_and_recognition_amd.modules.yolov5_face import preprocess_batch
+ydet = W.build_yolo_detector(dev, W.make_frames(4, dev, seed=6), "yolov5n", cand_per_frame=80)
+m = ydet.net
+yframes = W.make_frames(70, dev, seed=5)
+ybase = None
+for n in (8, 1, 3, 40, 70):
+    plan = preprocess_batch(m, yframes[:n], (640, 640))
+    z = m.run_plan(plan)
+    torch.cuda.synchronize()
+    cur = z[:min(n, 3)].cpu().numpy().copy()
+    if ybase is None: ybase = cur
+    else: print("yolov5n batch", n, "max |diff| of the decoded rows vs batch 8:", float(np.abs(cur[:min(n, 3)] - ybase[:min(n, 3)]).max()))
