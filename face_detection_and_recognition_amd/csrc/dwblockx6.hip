@@ -46,6 +46,10 @@ namespace {
 #ifndef FP_X6_DPRIO
 #define FP_X6_DPRIO 0
 #endif
+// Lab knob: the depthwise taps of dwblock_x6_kernel as plain instead of packed FMAs.
+#ifndef FP_X6_DSCALAR
+#define FP_X6_DSCALAR 0
+#endif
 #define X6_DPRIO_ON()  do { if (FP_X6_DPRIO) __builtin_amdgcn_s_setprio(FP_X6_DPRIO); } while (0)
 #define X6_DPRIO_OFF() do { if (FP_X6_DPRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 __device__ __forceinline__ int x6_tile_of_block() { return FP_X6_XCD ? (int)fp_xcd_block() : (int)blockIdx.x; }
@@ -137,7 +141,9 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
 
   // ---- staging: a round's expand weights (LDS-DMA, 1 KiB per wave and instruction) and parameters ----
   auto stage = [&](int s) {
-    const unsigned char* src = (const unsigned char*)p.we + (long)s * (K::WL * 2) + lane * 16;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // rebuilt per round: hoisted out of the round loop the address is one more live register pair, and a spill
+    const unsigned char* src = (const unsigned char*)p.we + (long)s * (K::WL * 2) + ln * 16;
 #pragma unroll
     for (int j = 0; j < K::WL * 2 / 4096; ++j) {
       const int chunk = j * 4 + wave;
@@ -236,9 +242,14 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
   };
 
   // D(s, c): 3x3 depthwise + BN + PReLU of chunk c's rows, E-image -> D-tile (three bf16 planes).
-  // lane = (channel pair c2, column strip): the window slides down the rows with 3 LDS reads per output.
+  // lane = (channel pair c2, column strip): the window slides down the rows, TWO output rows per step (two independent FMA
+  // chains), and the two E-image rows of the next step are requested between this step's FMAs and its BN / PReLU / split /
+  // stores, into the registers of the rows that just left the window.  hipcc keeps an LDS read behind every earlier LDS
+  // write (E-image and D-tile may alias for all it knows): with the reads at the top of each row the seven rows were seven
+  // serial round trips read -> 9 dependent FMAs -> split -> write (3000 cycles alone, 5300 beside the partner's MFMAs; FINDINGS 46)
   auto depthwise = [&](int s, auto cc) {
     constexpr int c = decltype(cc)::value;
+    constexpr int NR = K::crows(c);
     const float* Pc = Pl + (s & 1) * K::PL;
     const int c2 = tid & 15, strip = tid >> 4;
     f32x2 tap[9];
@@ -254,16 +265,25 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
         // E pixel (vr, col + dx - 1) is slot vr*ROWP + col + dx; output row r of the band reads vr = r, r + 1, r + 2
         const float* base = &El[(K::crow0(c) * K::ROWP + col) * K::LDE + 2 * c2];
         unsigned* dst = (unsigned*)Dl + (col * 32 + 2 * c2) / 2;
-        f32x2 w0[3], w1[3], w2[3];
+        auto ldrow = [&](int vr, f32x2* w) {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          w0[dx] = *(const f32x2*)(base + dx * K::LDE);
-          w1[dx] = *(const f32x2*)(base + (K::ROWP + dx) * K::LDE);
-        }
-#pragma unroll
-        for (int r = 0; r < K::crows(c); ++r) {
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) w2[dx] = *(const f32x2*)(base + ((r + 2) * K::ROWP + dx) * K::LDE);
+          for (int dx = 0; dx < 3; ++dx) w[dx] = *(const f32x2*)(base + (vr * K::ROWP + dx) * K::LDE);
+        };
+        auto taps = [&](const f32x2* w0, const f32x2* w1, const f32x2* w2) {
+#if FP_X6_DSCALAR
+          // lab: plain v_fma_f32 -- beside an MFMA stream a packed FMA retires every 22.5 cycles, a plain one every 8.7 (finding 24)
+          float a0, a1;
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a0) : "v"(w0[0][0]), "v"(tap[0][0]));
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a1) : "v"(w0[0][1]), "v"(tap[0][1]));
+#define X6_SFMA(W, T)                                                                  \
+  asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a0) : "v"((W)[0]), "v"((T)[0]));         \
+  asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a1) : "v"((W)[1]), "v"((T)[1]));
+          X6_SFMA(w0[1], tap[1]) X6_SFMA(w0[2], tap[2])
+          X6_SFMA(w1[0], tap[3]) X6_SFMA(w1[1], tap[4]) X6_SFMA(w1[2], tap[5])
+          X6_SFMA(w2[0], tap[6]) X6_SFMA(w2[1], tap[7]) X6_SFMA(w2[2], tap[8])
+#undef X6_SFMA
+          return f32x2{a0, a1};
+#else
           f32x2 sacc = w0[0] * tap[0];
           sacc += w0[1] * tap[1];
           sacc += w0[2] * tap[2];
@@ -271,6 +291,10 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
           for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+          return sacc;
+#endif
+        };
+        auto finish = [&](f32x2 sacc, int r) {
           f32x2 v = sacc * dsc + dbi;
           const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
           v = neg * dsl + v;
@@ -279,10 +303,30 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
           dst[(r * HW * 32) / 2] = h;
           dst[(K::DPL + r * HW * 32) / 2] = m;
           dst[(2 * K::DPL + r * HW * 32) / 2] = l;
+        };
+        f32x2 wa[3], wb[3], c0[3], c1[3];
+        ldrow(0, wa);
+        ldrow(1, wb);
+        ldrow(2, c0);
+        if (NR > 1) ldrow(3, c1);
+#pragma unroll
+        for (int r = 0; r < NR; r += 2) {
+          const f32x2 s0 = taps(wa, wb, c0);
+          f32x2 s1 = s0;
+          if (r + 1 < NR) s1 = taps(wb, c0, c1);
+          f32x2 na[3], nb[3];
+          if (r + 2 < NR) {
+            ldrow(r + 4, na);
+            if (r + 3 < NR) ldrow(r + 5, nb);
+          }
+          finish(s0, r);
+          if (r + 1 < NR) finish(s1, r + 1);
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
-            w0[dx] = w1[dx];
-            w1[dx] = w2[dx];
+            wa[dx] = c0[dx];
+            wb[dx] = c1[dx];
+            c0[dx] = na[dx];
+            c1[dx] = nb[dx];
           }
         }
       }
@@ -358,6 +402,21 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
   }
 
   // ---- epilogue: y = acc*s + b (+ x), lane = pixel l15 of the tile, channels 16 ct + 4 q .. + 3 ----
+  // every shortcut value is requested before the first one is used: one round trip to L2 / HBM for the tile instead of one
+  // per (chunk, channel tile)
+  f32x4 rv[K::NCHUNK][K::NCT][K::mtc(0)];
+#pragma unroll
+  for (int c = 0; c < K::NCHUNK; ++c)
+#pragma unroll
+    for (int j = 0; j < K::NCT; ++j) {
+      const int ch = 16 * (wave * K::NCT + j) + 4 * q;
+#pragma unroll
+      for (int t = 0; t < K::mtc(c); ++t) {
+        const int o = min(16 * t + l15, K::crows(c) * HW - 1);
+        const int off = ((r0 + K::crow0(c)) * HW + o) * C + ch;
+        rv[c][j][t] = p.has_res ? *(const f32x4*)(xin + off) : z;
+      }
+    }
 #pragma unroll
   for (int c = 0; c < K::NCHUNK; ++c) {
 #pragma unroll
@@ -365,18 +424,11 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
       const int ch = 16 * (wave * K::NCT + j) + 4 * q;
       const f32x4 ps = *(const f32x4*)(p.paff + ch);
       const f32x4 pb = *(const f32x4*)(p.paff + C + ch);
-      f32x4 rv[K::mtc(0)];
-#pragma unroll
-      for (int t = 0; t < K::mtc(c); ++t) {
-        const int o = min(16 * t + l15, K::crows(c) * HW - 1);
-        const int off = ((r0 + K::crow0(c)) * HW + o) * C + ch;
-        rv[t] = p.has_res ? *(const f32x4*)(xin + off) : z;
-      }
 #pragma unroll
       for (int t = 0; t < K::mtc(c); ++t) {
         const int o = 16 * t + l15;
         const int off = ((r0 + K::crow0(c)) * HW + o) * C + ch;
-        const f32x4 v = pacc[K::tbase(c) + t][j] * ps + pb + rv[t];
+        const f32x4 v = pacc[K::tbase(c) + t][j] * ps + pb + rv[c][j][t];
         if (o < K::crows(c) * HW) *(f32x4*)(yout + off) = v;
       }
     }
@@ -1207,16 +1259,18 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
         const int part = K::NPART > 1 && strip >= K::WO ? 1 : 0, col = strip - part * K::WO;
         const float* base = &El[((2 * K::RP * part) * K::ROWP + 2 * col) * K::LDE + 2 * c2];
         unsigned* dst = (unsigned*)Dl + ((K::RP * part * K::WO + col) * 32 + 2 * c2) / 2;
-        f32x2 w0[3], w1[3], w2[3];
+        // the two E-image rows of the next output row are requested between this row's FMAs and its BN / PReLU / split /
+        // stores (hipcc keeps an LDS read behind every earlier LDS write; see dwblock_x6_kernel's D phase)
+        auto ldrow = [&](int vr, f32x2* w) {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) w0[dx] = *(const f32x2*)(base + dx * K::LDE);
+          for (int dx = 0; dx < 3; ++dx) w[dx] = *(const f32x2*)(base + (vr * K::ROWP + dx) * K::LDE);
+        };
+        f32x2 w0[3], w1[3], w2[3];
+        ldrow(0, w0);
+        ldrow(1, w1);
+        ldrow(2, w2);
 #pragma unroll
         for (int r = 0; r < K::RP; ++r) {
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            w1[dx] = *(const f32x2*)(base + ((2 * r + 1) * K::ROWP + dx) * K::LDE);
-            w2[dx] = *(const f32x2*)(base + ((2 * r + 2) * K::ROWP + dx) * K::LDE);
-          }
           f32x2 sacc = w0[0] * tap[0];
           sacc += w0[1] * tap[1];
           sacc += w0[2] * tap[2];
@@ -1224,6 +1278,11 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
           for (int dx = 0; dx < 3; ++dx) sacc += w1[dx] * tap[3 + dx];
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) sacc += w2[dx] * tap[6 + dx];
+          f32x2 n1[3], n2[3];
+          if (r + 1 < K::RP) {
+            ldrow(2 * r + 3, n1);
+            ldrow(2 * r + 4, n2);
+          }
           f32x2 v = sacc * dsc + dbi;
           const f32x2 neg = {__builtin_fminf(v[0], 0.f), __builtin_fminf(v[1], 0.f)};
           v = neg * dsl + v;
@@ -1233,7 +1292,11 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6d_kernel(DwbX6Args p) {
           dst[(K::DPL + r * K::WO * 32) / 2] = m;
           dst[(2 * K::DPL + r * K::WO * 32) / 2] = l;
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) w0[dx] = w2[dx];
+          for (int dx = 0; dx < 3; ++dx) {
+            w0[dx] = w2[dx];
+            w1[dx] = n1[dx];
+            w2[dx] = n2[dx];
+          }
         }
       }
     }
