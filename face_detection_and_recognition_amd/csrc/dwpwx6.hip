@@ -79,6 +79,31 @@ __global__ __launch_bounds__(256, 2) void dwpwx6_kernel(DwPwX6Args p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] = z;
 
+  // the 3 x WIN window of this thread's item, one chunk of channels.  Stride 1 (PF): the window of chunk ch + 1 is requested
+  // right after the barrier that ends chunk ch's depthwise phase and lands under its MFMAs -- loaded at the top of the
+  // depthwise phase (the stride-2 form, whose 3 x 9 window leaves no registers for it) every chunk starts with an exposed
+  // round trip to L2
+  constexpr bool PF = S == 1;
+  f32x4 x[3][WIN];
+  auto load_x = [&](int ch) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = iy0 + ky;
+      const float* rowp = ib + KC * ch + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) {
+        const int ix = ix0 + j;
+        x[ky][j] = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);   // clamped; masked where it is used
+      }
+    }
+  };
+  unsigned inside = 0;                                   // bit ky * WIN + j: window element (ky, j) lies inside the image
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int j = 0; j < WIN; ++j)
+      inside |= (((unsigned)(iy0 + ky) < (unsigned)p.H) && ((unsigned)(ix0 + j) < (unsigned)p.W)) ? 1u << (ky * WIN + j) : 0u;
+
   const int nchunks = G / KC;
   for (int ch = 0; ch < nchunks; ++ch) {
     __syncthreads();                                     // parameters staged / the previous chunk's MFMAs are done with At and Bs
@@ -94,20 +119,11 @@ __global__ __launch_bounds__(256, 2) void dwpwx6_kernel(DwPwX6Args p) {
     // ---- depthwise + BN [+ PReLU] of channels 32 ch + 4 c4 .. + 3 for P pixels, split, -> At ----
     {
       const int c = KC * ch + 4 * c4;
-      f32x4 x[3][WIN];
+      if (!PF || ch == 0) load_x(ch);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = iy0 + ky;
-        const bool vy = (unsigned)iy < (unsigned)p.H;
-        const float* rowp = ib + KC * ch + (long)min(max(iy, 0), p.H - 1) * p.W * p.in_ld;
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int j = 0; j < WIN; ++j) {
-          const int ix = ix0 + j;
-          const bool v = vy && ((unsigned)ix < (unsigned)p.W);
-          const f32x4 t = *(const f32x4*)(rowp + (long)min(max(ix, 0), p.W - 1) * p.in_ld);
-          x[ky][j] = v ? t : z;
-        }
-      }
+        for (int j = 0; j < WIN; ++j) x[ky][j] = (inside >> (ky * WIN + j)) & 1u ? x[ky][j] : z;
       f32x4 a[P];
 #pragma unroll
       for (int k = 0; k < P; ++k) a[k] = z;
@@ -141,6 +157,7 @@ __global__ __launch_bounds__(256, 2) void dwpwx6_kernel(DwPwX6Args p) {
       }
     }
     __syncthreads();                                     // At complete, the weight slab landed (the barrier drains the DMA)
+    if (PF && ch + 1 < nchunks) load_x(ch + 1);
     // ---- 1x1: W^T (LDS) x A^T (LDS) for this wave's two pixel tiles ----
     {
       fp_frag3 af[2];
