@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void dwblock_x6_kernel(DwbX6Args p) {
   // chains), and the two E-image rows of the next step are requested between this step's FMAs and its BN / PReLU / split /
   // stores, into the registers of the rows that just left the window.  hipcc keeps an LDS read behind every earlier LDS
   // write (E-image and D-tile may alias for all it knows): with the reads at the top of each row the seven rows were seven
-  // serial round trips read -> 9 dependent FMAs -> split -> write (3000 cycles alone, 5300 beside the partner's MFMAs; FINDINGS 46)
+  // serial round trips read -> 9 dependent FMAs -> split -> write (3000 cycles alone, 5300 beside the partner's MFMAs; FINDINGS 47)
   auto depthwise = [&](int s, auto cc) {
     constexpr int c = decltype(cc)::value;
     constexpr int NR = K::crows(c);
