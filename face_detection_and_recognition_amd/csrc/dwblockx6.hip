@@ -601,9 +601,12 @@ __global__ __launch_bounds__(256, 3) void dwblock_x6q_kernel(DwbX6Args p) {
       const float* base = &El[col * K::LDE + ch];
       unsigned short* dst = Dl + (col * 32 + ch);
       float a0 = 0.f, a1 = 0.f, a2;   // a0: output i - 2 (complete after this row), a1: output i - 1, a2: output i
+      // row i + 1 is requested before row i's output is stored: hipcc keeps an LDS read behind every earlier LDS write (FINDINGS 47)
+      float n0 = base[0], n1 = base[K::LDE], n2 = base[2 * K::LDE];
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        const float x0 = base[(i * 9) * K::LDE], x1 = base[(i * 9 + 1) * K::LDE], x2 = base[(i * 9 + 2) * K::LDE];
+        const float x0 = n0, x1 = n1, x2 = n2;
+        if (i + 1 < 9) n0 = base[((i + 1) * 9) * K::LDE], n1 = base[((i + 1) * 9 + 1) * K::LDE], n2 = base[((i + 1) * 9 + 2) * K::LDE];
         if (i >= 2) {
           a0 = __builtin_fmaf(x0, tap[6], a0);
           a0 = __builtin_fmaf(x1, tap[7], a0);
