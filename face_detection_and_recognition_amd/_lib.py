@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfacepath.so")
 
 FP_OK = 0
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # fp_op_kind
 OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE2X, OP_COPY, OP_L2NORM, OP_BLAZEBLOCK, OP_DWPW, OP_YSTEM = 1, 2, 3, 4, 5, 6, 7, 8, 9

@@ -121,8 +121,9 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
   }
   if ((op.flags & FP_OPF_IN_DW) && (op.kind != FP_OP_DWBLOCK || !(op.flags & FP_OPF_SPLIT3))) return FP_ERR_INVALID_ARG;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind != FP_OP_DWBLOCK && op.kind != FP_OP_CONV && op.kind != FP_OP_DWPW && op.kind != FP_OP_BLAZECHAIN &&
-      op.kind != FP_OP_SHUFDOWN && op.kind != FP_OP_SHUFUNIT && op.kind != FP_OP_YSTEM2)
+      op.kind != FP_OP_SHUFDOWN && op.kind != FP_OP_SHUFUNIT && op.kind != FP_OP_YSTEM2 && op.kind != FP_OP_STEM_U8)
     return FP_ERR_INVALID_ARG;
+  if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_STEM_U8 && !fp_stem_u8_band_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_DWPW && !fp_dwpwx6_eligible(op)) return FP_ERR_UNSUPPORTED;
   if ((op.flags & FP_OPF_SPLIT3) && op.kind == FP_OP_CONV && !(op.flags & FP_OPF_OUT_DW) && !fp_pwx6_eligible(op) && !fp_convx6_eligible(op))
     return FP_ERR_UNSUPPORTED;
@@ -176,7 +177,8 @@ static int validate_op(const fp_op& op, size_t weight_floats, size_t arena_float
     if (op.kind != FP_OP_BLAZEBLOCK) {
       const int64_t K = (int64_t)op.KH * op.KW * (op.kind == FP_OP_STEM_U8 ? 4 : op.Cin);
       wext = ((K + 7) / 8 * 8) * ((op.Cout + 31) / 32 * 32);
-      if (op.flags & FP_OPF_SPLIT3) wext = fp_convx6_w_floats(op);   // three bf16 planes: 1.5 floats per (padded) weight
+      if (op.flags & FP_OPF_SPLIT3)     // three bf16 planes: 1.5 floats per (padded) weight; the u8 stem: [3 slabs][2][3][16][32] bf16
+        wext = op.kind == FP_OP_STEM_U8 ? 3 * 2 * 3 * 16 * 32 / 2 : fp_convx6_w_floats(op);
       if (op.flags & FP_OPF_OUT_DW) wext = fp_stemdw_w_floats(op);
     } else {
       // BLAZEBLOCK: dw weights [9][Cin] followed (separately addressed) by the packed 1x1; w_off addresses the
@@ -393,7 +395,7 @@ const char* fp_op_kernel_name(const fp_op* op) {
       return buf;
     case FP_OP_YSTEM2: return "ystem2_x6_kernel";
     case FP_OP_STEM_U8:
-      if (fp_stem_u8_band_eligible(*op)) return "stem5_u8_band_kernel";
+      if (fp_stem_u8_band_eligible(*op)) return (op->flags & FP_OPF_SPLIT3) ? "stem5_u8_x6_kernel" : "stem5_u8_band_kernel";
       snprintf(buf, sizeof(buf), "stem_conv_kernel<%d, %d, true>", op->KH, (int)fp_round_up(op->Cout, 32) / 32);
       return buf;
     case FP_OP_YSTEM:

@@ -15,8 +15,8 @@
 //               contiguous run (dense NHWC output: 128 x Cout floats)
 // k order and the packed weights are conv.hip's (k = tap*4 + c, zero rows up to Kpad): same products in the same
 // order, identical results.
-#include "common.h"
 #include "letterbox.h"
+#include "split.h"
 
 namespace {
 
@@ -503,6 +503,161 @@ __global__ __launch_bounds__(256, 3) void stem5_u8_band_kernel(StemBandArgs p) {
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The band form with the conv on the bf16 matrix cores (FP_OP_STEM_U8 + FP_OPF_SPLIT3; fp32-equivalent split arithmetic,
+// split.h).  The fp32 band kernel above is bound by its 39 fp32 MFMAs per 32 pixels: an fp32 MFMA is a vector-ALU
+// instruction of 64 cycles (FINDINGS 18), 168 of the kernel's 223 us.  Here
+//   * every canvas pixel is split ONCE, where it is resampled, and the ring holds three bf16 planes of dense RGB rows
+//     ([plane][8 rows][260 columns x 3 channels]): 14 VALU instructions per canvas pixel instead of 36 per gathered fragment;
+//   * K = 75 is ordered (ky, kx, c) with every ky padded to 16 (zero weights behind the 15): three 32-k slabs, slab s =
+//     canvas rows 2s and 2s + 1 of the window.  With stride 2 the 16 k of one ky are CONTIGUOUS in a ring row (offset 6 ox
+//     + 3 kx + c), so a lane's fragment (pixel l15 of a 16-pixel tile, 8 k) is 16 bytes at a 4-byte boundary: four
+//     ds_read_b32 per plane, no im2col;
+//   * D^T = W^T x A^T as everywhere: the weights (18 fragments of three planes, 72 registers) are the A operand, a lane ends
+//     up with four consecutive channels of ITS pixel and stores them straight to memory (16-byte pieces, 64 + 32 contiguous
+//     bytes per pixel: blazepair's direct store, FINDINGS 37);
+//   * 72 MFMAs of 16 cycles per wave and output row on the matrix pipe beside the resampling, against 39 of 64 on the
+//     vector ALU in front of it.
+// Products and sum order differ from the fp32 kernels: results agree to fp32 rounding, not bit for bit (tests: 1e-5 of the
+// output scale against the fp32 band kernel, and the reference goldens through the whole detector).
+namespace {
+
+constexpr int SX_ROWE = SB_WP * 3;            // bf16 elements per ring row (260 columns x 3 channels)
+constexpr int SX_PL = 8 * SX_ROWE;            // per plane
+static_assert((SX_ROWE * 2) % 4 == 0, "ring rows start at 4-byte boundaries");
+
+__global__ __launch_bounds__(256, 3) void stem5_u8_x6_kernel(StemBandArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_x6[];
+  unsigned short* Ring = (unsigned short*)smem_x6;                 // [3][8][SX_ROWE] bf16
+  float* LutS = (float*)(Ring + 3 * SX_PL);                        // [256]
+  fp_lb_tap* TabS = (fp_lb_tap*)(LutS + 256);                      // [512]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+  if (!fp_lb_geometry_ok(p.tabs, SB_W, SB_W, p.frame_h, p.frame_w)) return;   // tables of another geometry (uniform)
+  LutS[tid] = p.lut[tid];
+  for (int i = tid; i < 2 * SB_W; i += 256) TabS[i] = p.tabs[i];
+  const fp_lb_tap tr = p.tabs[2 * SB_W];
+  const int pad_value = tr.a, swap_rb = tr.b;
+  for (int i = tid; i < 3 * SX_PL / 2; i += 256) ((unsigned*)Ring)[i] = 0u;   // borders (columns -1, 256 .. 258) stay zero
+
+  // weights: slab s, channel tile nt (16 nt + l15), plane, k = 8 q .. + 7 of the slab.  Blob: [3 s][2 nt][3 planes][16][32] bf16
+  fp_frag3 w3[3][2];
+  {
+    const unsigned short* wp = (const unsigned short*)p.w;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const unsigned short* b = wp + (((sl * 2 + nt) * 3) * 16 + l15) * 32 + 8 * q;
+        w3[sl][nt].h = *(const u32x4*)b;
+        w3[sl][nt].m = *(const u32x4*)(b + 16 * 32);
+        w3[sl][nt].l = *(const u32x4*)(b + 2 * 16 * 32);
+      }
+  }
+  f32x4 bias4[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bias4[nt] = (nt == 0 || q < 2) ? *(const f32x4*)(p.bias + 16 * nt + 4 * q) : z4;
+
+  const int img = blockIdx.x / p.bands, band = blockIdx.x - img * p.bands;
+  const int oy0 = band * p.R;
+  const uint8_t* frame = p.frames + (long)img * p.frame_bytes;
+  float* outi = p.out + (long)img * p.out_ns;
+  __syncthreads();
+
+  // canvas row iy (column tid) -> ring: resampled inside the canvas (zero outside it: the conv's F.pad(1, 2, 1, 2)), split
+  // into its three bf16 pieces, 3 x 3 two-byte stores
+  const fp_lb_tap xt = TabS[tid];
+  auto put = [&](int iy, const f32x4 v) {
+    unsigned h01, m01, l01, h2, m2, l2;
+    fp_split_pair(v[0], v[1], h01, m01, l01);
+    fp_split_one(v[2], h2, m2, l2);
+    unsigned short* d = Ring + (iy & 7) * SX_ROWE + (1 + tid) * 3;
+    d[0] = (unsigned short)h01, d[1] = (unsigned short)(h01 >> 16), d[2] = (unsigned short)h2;
+    d[SX_PL] = (unsigned short)m01, d[SX_PL + 1] = (unsigned short)(m01 >> 16), d[SX_PL + 2] = (unsigned short)m2;
+    d[2 * SX_PL] = (unsigned short)l01, d[2 * SX_PL + 1] = (unsigned short)(l01 >> 16), d[2 * SX_PL + 2] = (unsigned short)l2;
+  };
+  auto issue_rows = [&](int iy0, fp_lb_raw (&raw)[2]) {          // rows iy0, iy0 + 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) raw[j] = fp_lb_issue(frame, p.row_bytes, xt, TabS[SB_W + min(max(iy0 + j, 0), SB_W - 1)]);
+  };
+  auto finish_rows = [&](int iy0, const fp_lb_raw (&raw)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = iy0 + j;
+      const f32x4 v = fp_lb_finish(raw[j], xt, TabS[SB_W + min(max(iy, 0), SB_W - 1)], LutS, pad_value, swap_rb);
+      put(iy, (unsigned)iy < (unsigned)SB_W ? v : z4);
+    }
+  };
+  fp_lb_raw rawa[2];
+  // band prologue: rows 2*oy0 - 1 .. 2*oy0 + 3 (the pair starting at 2*oy0 + 4 belongs to the first step)
+  issue_rows(2 * oy0 - 1, rawa);
+  finish_rows(2 * oy0 - 1, rawa);
+  issue_rows(2 * oy0 + 1, rawa);
+  finish_rows(2 * oy0 + 1, rawa);
+  {
+    const int iy = 2 * oy0 + 3, iyc = min(iy, SB_W - 1);
+    const fp_lb_tap yt = TabS[SB_W + iyc];
+    const fp_lb_raw r = fp_lb_issue(frame, p.row_bytes, xt, yt);
+    const f32x4 v = fp_lb_finish(r, xt, yt, LutS, pad_value, swap_rb);
+    put(iy, iy < SB_W ? v : z4);
+  }
+  __syncthreads();
+
+  // this lane's fragments: output pixel ox = 32 wave + 16 t + l15 -> ring offset 6 ox (+ 8 for the second half of a ky's 16 k)
+  const int frag_off = 6 * (32 * wave + l15) + 8 * (q & 1);
+  for (int s = 0; s < p.R; ++s) {
+    const int oy = oy0 + s;
+    const int r0 = 2 * oy - 1;                           // first of the 5 canvas rows of this output row
+    const bool more = s + 1 < p.R;
+    if (more) issue_rows(r0 + 5, rawa);                  // rows 2oy + 4, 2oy + 5: in flight during the MFMAs (requesting them a
+                                                         // step earlier changes nothing: 196-201 against 190 us, same step time)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = z4;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      // slab sl: canvas rows r0 + 2 sl (k 0 .. 15) and r0 + 2 sl + 1 (k 16 .. 31); the sixth row does not exist (zero weights:
+      // any finite data will do -> row 4 again)
+      const int ky = min(2 * sl + (q >> 1), 4);
+      const unsigned short* rowp = Ring + ((r0 + ky) & 7) * SX_ROWE + frag_off;
+      fp_frag3 pf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned* a = (const unsigned*)(rowp + 96 * t);      // 16 pixels further: 6 x 16 elements
+        const unsigned* b = (const unsigned*)(rowp + 96 * t + SX_PL);
+        const unsigned* c = (const unsigned*)(rowp + 96 * t + 2 * SX_PL);
+        pf[t].h = u32x4{a[0], a[1], a[2], a[3]};
+        pf[t].m = u32x4{b[0], b[1], b[2], b[3]};
+        pf[t].l = u32x4{c[0], c[1], c[2], c[3]};
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fp_mfma_x6_2a(w3[sl][0], w3[sl][1], pf[t].h, pf[t].m, pf[t].l, acc[t][0], acc[t][1]);
+    }
+    if (more) finish_rows(r0 + 5, rawa);                 // other rows than the ones any wave is reading in this step
+    // bias + ReLU, lane (l15, q): pixel 32 wave + 16 t + l15, channels 16 nt + 4 q .. + 3 (nt = 1: q < 2)
+    float* orow = outi + (long)oy * p.out_rp + (32 * wave + l15) * SB_C + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc[t][nt][e] + bias4[nt][e];
+          v[e] = x > 0.f ? x : 0.f;
+        }
+        if (nt == 0 || q < 2) *(f32x4*)(orow + 16 * t * SB_C + 16 * nt) = v;
+      }
+    __syncthreads();                                     // the next step reads the rows just written
+  }
+}
+
+}  // namespace
+
 bool fp_stem_u8_band_eligible(const fp_op& op) {
   return op.kind == FP_OP_STEM_U8 && op.KH == 5 && op.KW == 5 && op.stride == 2 && op.pad_t == 1 && op.pad_l == 1 &&
          op.H == SB_W && op.W == SB_W && op.OH == SB_OW && op.OW == SB_OW && op.Cout == SB_C && op.out_ld == SB_C &&
@@ -529,6 +684,12 @@ int fp_launch_stem_u8_band(const fp_op& op, const float* weights, float* arena, 
 #endif
   a.R = FP_STEM_BAND_ROWS;
   a.bands = SB_OW / a.R;
+  if (op.flags & FP_OPF_SPLIT3) {
+    const size_t lds6 = (size_t)3 * SX_PL * 2 + 256 * 4 + 8 * (size_t)(2 * SB_W);
+    hipLaunchKernelGGL(stem5_u8_x6_kernel, dim3(op.N * a.bands), dim3(256), lds6, s, a);
+    FP_CHECK_LAUNCH();
+    return FP_OK;
+  }
   const size_t lds = 4 * ((size_t)8 * SB_WP * 4 + 4 * 32 * SB_C + 256) + 8 * (size_t)(2 * SB_W);
   hipLaunchKernelGGL(stem5_u8_band_kernel, dim3(op.N * a.bands), dim3(256), lds, s, a);
   FP_CHECK_LAUNCH();

@@ -173,6 +173,11 @@ class BlazeFace(nn.Module):
     with r (b, 896, 16) and c (b, 896, 1); ``predict_on_batch`` returns a list of (k, 17) tensors
     (ymin, xmin, ymax, xmax, 6 keypoints, score)."""
 
+    # class-wide switch: the back model's 5 x 5 stem on u8 frames on the bf16 matrix cores (FP_OP_STEM_U8 + FP_OPF_SPLIT3,
+    # stem5_u8_x6_kernel; needs PlanBuilder.X6 as every split kernel does).  False: the fp32-MFMA band kernel, whose results are
+    # bit-identical to the stand-alone letterbox + conv (the tests of that identity switch it off)
+    STEM_X6 = os.environ.get("FP_BLAZE_STEM_X6", "1") == "1"
+
     def __init__(self, back_model=False):
         super().__init__()
         self.num_classes = 1
@@ -285,8 +290,9 @@ class BlazeFace(nn.Module):
         if frame_hw is None:
             pb.conv(inp.view(), npy(stem.weight), x.view(), stride=2, pad=(1, 1), bias=npy(stem.bias), act=L.ACT_RELU)
         else:
+            split = BlazeFace.STEM_X6 and PlanBuilder.X6 and (H, W) == (256, 256) and N >= 16
             pb.stem_u8((H, W, frame_hw[0], frame_hw[1], 0), npy(stem.weight), x.view(), pad=(1, 1), bias=npy(stem.bias),
-                       act=L.ACT_RELU)
+                       act=L.ACT_RELU, split=split)
         i = 0
         while i < len(blocks):
             blk = blocks[i]

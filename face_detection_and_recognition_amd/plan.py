@@ -830,7 +830,24 @@ class PlanBuilder:
         self.alg_bytes.append(4 * self.N * pix * 6 * cb)     # SURVEY 8(d): three convs of cb channels, input once + output once each
         return out
 
-    def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE):
+    @staticmethod
+    def pack_stem5_x6(w):
+        """[24, 3, 5, 5] -> the three bf16 planes of stem5_u8_x6_kernel (csrc/stem.hip): [3 slabs][2 channel tiles][3 planes][16][32]
+        with k = 16 (ky - 2 slab) + 3 kx + c inside a slab (every ky padded to 16, the sixth ky and channels 24 .. 31 zero)."""
+        w = np.asarray(w, dtype=np.float32)
+        assert w.shape == (24, 3, 5, 5)
+        full = np.zeros((3, 2, 16, 32), dtype=np.float32)               # [slab][nt][channel][k]
+        for ky in range(5):
+            for kx in range(5):
+                for c in range(3):
+                    k = 16 * (ky % 2) + 3 * kx + c
+                    for co in range(24):
+                        full[ky // 2, co // 16, co % 16, k] = w[co, c, ky, kx]
+        planes = split3_bf16(full)                                      # [3 planes][slab][nt][16][32]
+        blob = np.ascontiguousarray(planes.transpose(1, 2, 0, 3, 4))    # [slab][nt][plane][16][32]
+        return blob.reshape(-1).view(np.float32)
+
+    def stem_u8(self, u8, w, out, pad=(0, 0), scale=None, bias=None, slope=None, act=L.ACT_NONE, split=False):
         """First conv of a network reading u8 frames itself (FP_OP_STEM_U8): KxK (3 or 5) stride 2, Cout <= 64, dense
         output buffer.  u8 = (H, W, frame_h, frame_w, ext_index): the H x W letterbox canvas is resampled from the
         frames while the conv's input tile is staged (external buffers ext_index..+2 = frames, tap tables, LUT).
@@ -851,7 +868,14 @@ class PlanBuilder:
         op.act = act
         op.res_H, op.res_W = fh, fw
         op.w_off = op.scale_off = op.bias_off = op.slope_off = -1
-        op.w_off = self.add_weight(pack_conv_weight(w, 4, out.C))
+        if split:
+            # BlazeFace's 5x5 stem on the bf16 matrix cores (FP_OPF_SPLIT3, stem5_u8_x6_kernel): the band form's shape only
+            assert (kh, H, W, out.H, out.W, cout) == (5, 256, 256, 128, 128, 24) and pad == (1, 1) and scale is None
+            assert bias is not None and act == L.ACT_RELU and self.N >= 16
+            op.flags |= L.OPF_SPLIT3
+            op.w_off = self.add_weight(self.pack_stem5_x6(w))
+        else:
+            op.w_off = self.add_weight(pack_conv_weight(w, 4, out.C))
         if scale is not None:
             op.scale_off = self.add_weight(pad_vec(scale, out.C, 0.0))
         if bias is not None:

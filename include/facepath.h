@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FP_ABI_VERSION 10
+#define FP_ABI_VERSION 11
 
 typedef enum fp_status {
   FP_OK = 0,
@@ -177,7 +177,10 @@ typedef struct fp_op {
  *                + channel in slabs of 32) (weights [tap * ceil(Cin / 32) + slab][3
  *                planes][Npad][32] bf16, zero rows / columns in the padding); FP_OP_DWPW 3x3 pad 1 with Cin a multiple of
  *                32 (<= 256) and Cout 64 or 128; FP_OP_BLAZECHAIN (always); FP_OP_CONV with
- *                FP_OPF_OUT_DW (planes [Cout / 16][3][16][32] over k = tap * 3 + channel).  The semantics of the ops do not change.
+ *                FP_OPF_OUT_DW (planes [Cout / 16][3][16][32] over k = tap * 3 + channel); FP_OP_STEM_U8 (ABI 11) in BlazeFace's
+ *                band shape only (5x5 stride 2 pad 1 on a 256 x 256 canvas, Cout 24, bias + ReLU, N >= 16: stem5_u8_x6_kernel) with
+ *                planes [3 slabs][2 channel tiles][3 planes][16][32] over k = 16 (ky - 2 slab) + 3 kx + channel (every ky padded
+ *                to 16 k, the sixth ky and channels 24 .. 31 zero).  The semantics of the ops do not change.
  */
 #define FP_OPF_SPLIT3 8
 /*
@@ -289,7 +292,7 @@ typedef struct fp_op {
  *            [32] scale, [32] bias;  [2 slabs][3 planes][32 co][32 k] stem_3 (k: stem_2b's 32 channels, then the pooled map's);  [32] scale,
  *            [32] bias (scale = 1 where the BatchNorm is folded into the conv).
  * ABI history: 1 = round-1 ops; 2 = fp_ext / *_U8 ops (never shipped in a VERDICT-ed tree); 3 = fp_op.flags, row-padded
- * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env; 10 = FP_OP_SHUFDOWN, FP_OP_SHUFUNIT, FP_OP_YSTEM2.
+ * views; 4 = fp_op.Cmid / reserved0, FP_OP_DWBLOCK, FP_OP_BLAZEPAIR; 5 = FP_OPF_SPLIT3; 6 = FP_OP_BLAZECHAIN; 7 = FP_OPF_IN_UP2; 8 = FP_OP_BLAZEPAIR with stride 2; 9 = FP_OPF_OUT_DW, fp_debug_reload_env; 10 = FP_OP_SHUFDOWN, FP_OP_SHUFUNIT, FP_OP_YSTEM2; 11 = FP_OPF_SPLIT3 on FP_OP_STEM_U8.
  */
 
 /* Validates every op against arena_floats / weight_floats, then launches them in order. */

@@ -119,20 +119,26 @@ def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw, n
     net.set_anchors(generate_anchors(back))
     model = BlazeFaceModel("", 0.7, 0.12, "back" if back else "front", device=str(dev), net=net)
     outs = {}
-    for flag in (True, False):
-        B.BlazeFace.FUSE_LETTERBOX = flag
+    stem_x6 = B.BlazeFace.STEM_X6
+    for flag in (True, False, "x6"):
+        B.BlazeFace.FUSE_LETTERBOX = bool(flag)
+        B.BlazeFace.STEM_X6 = flag == "x6"       # the fp32 stems are the bit-identical ones; the split-MFMA band stem below
         try:
             model.raw_batch(frames)
             torch.cuda.synchronize()
-            assert (net.last_plan.input is None) == flag
+            assert (net.last_plan.input is None) == bool(flag)
             if flag:
-                assert net.last_plan.kernel_name(0) == ("stem5_u8_band_kernel" if back and nf >= 16 else
-                                                        "stem_conv_kernel<5, 1, true>")
+                band = "stem5_u8_x6_kernel" if flag == "x6" else "stem5_u8_band_kernel"
+                assert net.last_plan.kernel_name(0) == (band if back and nf >= 16 else "stem_conv_kernel<5, 1, true>")
             outs[flag] = (net.last_plan.r.clone().cpu().numpy(), net.last_plan.c.clone().cpu().numpy())
         finally:
             B.BlazeFace.FUSE_LETTERBOX = True
+            B.BlazeFace.STEM_X6 = stem_x6
     np.testing.assert_array_equal(outs[True][0], outs[False][0])
     np.testing.assert_array_equal(outs[True][1], outs[False][1])
+    # FP_OPF_SPLIT3 on the band stem (stem5_u8_x6_kernel: the conv on the bf16 matrix cores, fp32-equivalent split arithmetic):
+    # the same raw outputs to fp32 rounding through the whole network
+    assert rel_err(outs["x6"][0], outs[False][0]) < 1e-5 and rel_err(outs["x6"][1], outs[False][1]) < 1e-5
 
 
 def test_u8_stems_refuse_tap_tables_of_another_geometry(dev, lib):
@@ -2116,7 +2122,7 @@ def test_full_size_config1_step_sampled_frames_vs_oracle(dev):
     plan = pipe.emb_plan
     assert plan.N % 256 == 0 and plan.N >= n and L.OP_DWBLOCK in [plan.ops[i].kind for i in range(plan.n_ops)]
     names = [det.net.last_plan.kernel_name(i) for i in range(det.net.last_plan.n_ops)]
-    assert names[0] == "stem5_u8_band_kernel" and names.count("blazepair_kernel<128>") == 3
+    assert names[0] == "stem5_u8_x6_kernel" and names.count("blazepair_kernel<128>") == 3
     e = out["emb"].cpu().numpy()
     info = out["info"].cpu().numpy()
     np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)
