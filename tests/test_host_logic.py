@@ -488,6 +488,42 @@ def test_fused_letterbox_plans_validate_on_host(lib):
     assert lib.fp_letterbox_tables(70000, 1024, 640, 640, 0, 0, 1024, 70000, 0, 0, 640, 640, 125, 1, buf, None) != 0
 
 
+def test_split_stem_packing_and_validation(lib):
+    """FP_OPF_SPLIT3 on FP_OP_STEM_U8 (ABI 11, stem5_u8_x6_kernel): PlanBuilder.pack_stem5_x6 lays the 24 x 3 x 5 x 5 weights out as
+    [3 slabs][2 channel tiles][3 planes][16][32] bf16 with k = 16 (ky - 2 slab) + 3 kx + c -- the three planes add up to the fp32
+    weight exactly, every other position (k = 15 and 31 of a slab, the sixth ky, channels 24 .. 31) is zero; the back model's plan
+    carries the flag from batch 16 on (with PlanBuilder.X6 and BlazeFace.STEM_X6), validates, and the flag is refused on the
+    stem of any other shape."""
+    from face_detection_and_recognition_amd.plan import PlanBuilder
+    w = np.random.default_rng(5).normal(0, 0.3, (24, 3, 5, 5)).astype(np.float32)
+    blob = PlanBuilder.pack_stem5_x6(w)
+    assert blob.dtype == np.float32 and blob.size == 3 * 2 * 3 * 16 * 32 // 2
+    planes = blob.view(np.uint16).reshape(3, 2, 3, 16, 32).astype(np.uint32) << 16       # [slab][nt][plane][co % 16][k]
+    rebuilt = planes.view(np.float32).sum(axis=2)                                       # h + m + l (exact in fp32: split3_bf16)
+    seen = np.zeros_like(rebuilt, dtype=bool)
+    for ky in range(5):
+        for kx in range(5):
+            for c in range(3):
+                k = 16 * (ky % 2) + 3 * kx + c
+                np.testing.assert_array_equal(rebuilt[ky // 2, :, :, k].reshape(32)[:24], w[:, c, ky, kx])
+                seen[ky // 2, :, :, k].reshape(32)[:24] = True
+    assert (rebuilt[~seen] == 0).all()
+    for n, flagged in ((3, False), (16, True), (256, True)):
+        pb = BlazeFace(True)._emit(n, frame_hw=(576, 1024))[0]
+        assert bool(pb.ops[0].flags & L.OPF_SPLIT3) == flagged and validate_on_host(pb) == 0
+    pb = BlazeFace(False)._emit(16, frame_hw=(576, 1024))[0]                                 # front model: 128 x 128 canvas
+    assert not (pb.ops[0].flags & L.OPF_SPLIT3) and validate_on_host(pb) == 0
+    pb.ops[0].flags |= L.OPF_SPLIT3
+    assert validate_on_host(pb) == -3                                                        # FP_ERR_UNSUPPORTED
+    old = BlazeFace.STEM_X6
+    try:
+        BlazeFace.STEM_X6 = False
+        pb = BlazeFace(True)._emit(16, frame_hw=(576, 1024))[0]
+        assert not (pb.ops[0].flags & L.OPF_SPLIT3) and validate_on_host(pb) == 0
+    finally:
+        BlazeFace.STEM_X6 = old
+
+
 def test_split3_plan_layouts_and_validation():
     """FP_OPF_SPLIT3 on the host: the weight planes PlanBuilder packs for the split-MFMA ops rebuild the fp32 weights
     exactly in the layouts include/facepath.h documents, every network plan validates with the split kernels on and off,
