@@ -105,7 +105,8 @@ def test_blazeface_fused_and_unfused_plans_agree(dev, back):
 
 @pytest.mark.parametrize("back,frame_hw,nf", [(True, (576, 1024), 5), (False, (576, 1024), 5), (True, (97, 33), 5),
                                               (True, (300, 211), 5), (False, (1275, 1650), 5),
-                                              (True, (576, 1024), 21), (True, (211, 300), 16)])   # >= 16 frames: stem5_u8_band_kernel
+                                              (True, (576, 1024), 21), (True, (211, 300), 16),
+                                              (True, (1024, 576), 17)])   # >= 16 frames: the band stems (fp32 MFMA / split MFMA); the last one a portrait frame: padding left and right
 def test_blazeface_letterbox_fused_into_stem_is_bit_exact(dev, back, frame_hw, nf):
     """FP_OP_STEM_U8 (the 5x5 stem resamples the u8 frames through fp_letterbox_tables while it stages its input;
     no fp32 canvas) against the stand-alone letterbox kernel + the fp32 stem: identical raw network outputs."""
